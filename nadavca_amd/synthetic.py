@@ -1,0 +1,128 @@
+"""Deterministic synthetic workloads for tests and bench.py (recipe: SURVEY.md §8d).
+
+Nothing here comes from the reference: there is no sample data offline, so reads are
+simulated from a k-mer table — per base a dwell of U{lo..hi} samples at the k-mer's
+expected level plus Gaussian noise, anchors = a random subset of the true
+base->sample map, jittered, exactly the shape
+``ApproximateAligner.get_signal_alignment`` hands to the DP
+(/root/reference/nadavca/alignment.py:142-186).
+"""
+import os
+
+import numpy as np
+
+from . import defaults
+
+
+def load_model_arrays(path=None):
+    """-> (k, central_position, alphabet_size, mean[4^k], sigma[4^k]) from an .npz table."""
+    z = np.load(path or defaults.KMER_MODEL_FILE)
+    return int(z['k']), int(z['central_pos']), int(z['alphabet_size']), \
+        np.array(z['mean'], dtype=np.float64), np.array(z['sigma'], dtype=np.float64)
+
+
+def synth_model_arrays(seed=0, k=6, central=2, alphabet=4):
+    """A random table with the real 6-mer table's moments (mean sd 1.26, sigma 0.33288)."""
+    rng = np.random.default_rng(seed)
+    n = alphabet ** k
+    return k, central, alphabet, rng.normal(0.0, 1.26, n), np.full(n, 0.3328800486427912)
+
+
+def kmer_ids(seq_ext, offset, length, k, central, alphabet=4):
+    """k-mer id of positions 0..length-1 of the sequence that starts at ``offset`` inside
+    ``seq_ext`` (out-of-range bases read as 0, as the reference's ExtendedSequence does)."""
+    seq_ext = np.asarray(seq_ext, dtype=np.int64)
+    ids = np.zeros(length, dtype=np.int64)
+    pos = np.arange(length) + offset - central
+    for m in range(k):
+        p = pos + m
+        ok = (p >= 0) & (p < seq_ext.size)
+        b = np.where(ok, seq_ext[np.clip(p, 0, max(seq_ext.size - 1, 0))] if seq_ext.size else 0, 0)
+        ids = ids * alphabet + b
+    return ids
+
+
+def make_dp_case(rng, model, R=400, bandwidth=150, dwell=(3, 17), noise=0.35,
+                 anchor_density=0.75, jitter=20, with_context=True, trim=3, pad_bases=None):
+    """One DP problem in the argument shape of ``dtw.refine_alignment`` /
+    ``dtw.estimate_log_likelihoods``.  Returns a dict with signal (f64), reference,
+    context_before, context_after (int32), approximate_alignment (int32 (A,2)),
+    and the true event starts (slice coordinates) for sanity checks."""
+    k, central, alphabet, mean, sigma = model
+    lo, hi = dwell
+    if pad_bases is None:
+        pad_bases = int(np.ceil(bandwidth / ((lo + hi) / 2.0))) + 6
+    full = rng.integers(0, alphabet, R + 2 * pad_bases)
+    ids = kmer_ids(full, 0, full.size, k, central, alphabet)
+    dw = rng.integers(lo, hi + 1, full.size)
+    starts = np.concatenate([[0], np.cumsum(dw)])
+    total = int(starts[-1])
+    x = np.repeat(mean[ids], dw) + rng.normal(0.0, noise, total)
+    x = np.clip(x, -5.0, 5.0)
+
+    # anchors: matched bases of the R-base segment, thinned, jittered, monotone
+    cand = np.arange(trim, R - trim) if R > 2 * trim + 1 else np.arange(R)
+    keep = cand[rng.random(cand.size) < anchor_density]
+    keep = np.unique(np.concatenate([[0], keep, [R - 1]])) if R > 0 else keep
+    sig_idx = starts[pad_bases + keep] + rng.integers(-jitter, jitter + 1, keep.size)
+    sig_idx = np.maximum.accumulate(np.clip(sig_idx, 0, total - 1))
+    s_first, s_last = int(sig_idx[0]), int(sig_idx[-1])
+    a0 = max(0, s_first - bandwidth)
+    a1 = min(total, s_last + 1 + bandwidth)
+    anchors = np.stack([sig_idx - a0, keep], axis=1).astype(np.int32)
+    ref = full[pad_bases:pad_bases + R].astype(np.int32)
+    if with_context:
+        cb = full[pad_bases - central:pad_bases].astype(np.int32)
+        ca = full[pad_bases + R:pad_bases + R + k - central - 1].astype(np.int32)
+    else:
+        cb = np.zeros(0, dtype=np.int32)
+        ca = np.zeros(0, dtype=np.int32)
+    return dict(signal=np.ascontiguousarray(x[a0:a1]), reference=ref, context_before=cb,
+                context_after=ca, approximate_alignment=anchors,
+                true_starts=(starts[pad_bases:pad_bases + R + 1] - a0).astype(np.int64))
+
+
+class Batch:
+    """Flat (CSR-style) batch of DP problems — the layout of the C-ABI batch calls
+    (include/nadavca_hip.h)."""
+
+    def __init__(self, cases):
+        self.n = len(cases)
+        self.cases = cases
+        cat = lambda key, dt: (np.concatenate([np.asarray(c[key]).reshape(-1) for c in cases]).astype(dt)
+                               if cases else np.zeros(0, dtype=dt))
+        off = lambda key, div=1: np.concatenate(
+            [[0], np.cumsum([np.asarray(c[key]).size // div for c in cases])]).astype(np.int64)
+        self.signal = cat('signal', np.float64)
+        self.sig_off = off('signal')
+        self.reference = cat('reference', np.int32)
+        self.ref_off = off('reference')
+        self.context_before = cat('context_before', np.int32)
+        self.cb_off = off('context_before')
+        self.context_after = cat('context_after', np.int32)
+        self.ca_off = off('context_after')
+        self.anchors = cat('approximate_alignment', np.int32)
+        self.anc_off = off('approximate_alignment', 2)
+
+
+def make_batch(n_reads, model, seed=0, R=400, R_spread=40, **kw):
+    """``n_reads`` independent DP problems, read i drawn from default_rng([seed, i])."""
+    cases = []
+    for i in range(n_reads):
+        rng = np.random.default_rng([seed, i])
+        r = int(R + rng.integers(-R_spread, R_spread + 1)) if R_spread else int(R)
+        cases.append(make_dp_case(rng, model, R=r, **kw))
+    return Batch(cases)
+
+
+# BASELINE.json configs 2-5 (sizes: SURVEY.md §8 header)
+WORKLOADS = {
+    'cfg2_align': dict(n_reads=10000, R=400, R_spread=40, bandwidth=150),
+    'cfg3_snps': dict(n_reads=10000, R=400, R_spread=40, bandwidth=150),
+    'cfg5_long': dict(n_reads=64, R=5000, R_spread=500, bandwidth=1000),
+}
+
+
+def env_int(name, default):
+    v = os.environ.get(name)
+    return int(v) if v else default
