@@ -1,0 +1,181 @@
+/*
+ * nadavca_hip.h — C ABI of libnadavca_hip.so, the MI355X (gfx950) engine behind
+ * Nadavca's signal-to-reference alignment operators.
+ *
+ * This is the drop-in boundary for the reference's pybind11 module `nadavca.dtw`
+ * (/root/reference/nadavca/dtw/dtwmodule.cpp:10-29; C++ declarations in
+ * /root/reference/nadavca/dtw/dtw.h:6-18 and kmer_model.h:18-25).  Every entry
+ * point below names the reference interface it replaces.  Plain pointers and
+ * sizes only; the caller owns every buffer it passes, the library keeps nothing
+ * past the call except what hangs off the opaque handles.
+ *
+ * Batched, flat ("CSR") argument layout.  A batch of n reads is described by
+ *   signal      f64[ sig_off[n] ]      samples of read j: [sig_off[j], sig_off[j+1])
+ *   reference   i32[ ref_off[n] ]      bases 0..alphabet-1
+ *   ctx_before  i32[ cb_off[n] ]       k-mer context left of the reference part
+ *   ctx_after   i32[ ca_off[n] ]       k-mer context right of it
+ *   anchors     i32[ 2*anc_off[n] ]    rows (signal_index_in_slice, reference_index)
+ *   *_off       i64[n+1]               exclusive prefix sums, off[0] = 0
+ * which is the per-read argument list of the reference (signal, reference,
+ * context_before, context_after, approximate_alignment) concatenated over reads.
+ *
+ * Two flavours of each operator:
+ *   nvk_xxx_batch      host pointers   (stages H2D, runs, copies results back)
+ *   nvk_xxx_batch_dev  device pointers (inputs already resident in HBM; runs on the
+ *                      context's HIP stream; results are complete on return)
+ *
+ * There is NO CPU fallback: without a usable HIP device every compute call
+ * returns NVK_ERR_NO_DEVICE.
+ */
+#ifndef NADAVCA_HIP_H
+#define NADAVCA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nvk_ctx nvk_ctx;     /* one per process/GPU: stream, workspaces, timers */
+typedef struct nvk_model nvk_model; /* device-resident k-mer table, bound to a ctx */
+
+/* call status */
+enum {
+  NVK_OK = 0,
+  NVK_ERR_NO_DEVICE = -1,   /* no HIP device / runtime failure at init */
+  NVK_ERR_INVALID = -2,     /* bad argument (see nvk_last_error) */
+  NVK_ERR_HIP = -3,         /* a HIP call failed */
+  NVK_ERR_UNSUPPORTED = -4, /* parameter outside the compiled range */
+  NVK_ERR_NOMEM = -5
+};
+
+/* per-read status written by the batch operators */
+enum {
+  NVK_READ_OK = 0,
+  NVK_READ_NO_PATH = 1,       /* reference: refine_alignment returns [] (dtw.cpp:211-213) */
+  NVK_READ_BAD_INPUT = -1,    /* empty reference/signal, anchor outside the reference */
+  NVK_READ_BAD_BAND = -2      /* band_end < band_start for some row (reference: UB / length_error) */
+};
+
+/* kernel ids for nvk_timing_read */
+enum {
+  NVK_K_PLAN = 0,        /* band + row-table planner */
+  NVK_K_ALIGN = 1,       /* banded forward-backward + path search (refine_alignment) */
+  NVK_K_ELL_SWEEP = 2,   /* prefix/suffix sweeps of estimate_log_likelihoods */
+  NVK_K_ELL_HYP = 3,     /* per-base substitution hypotheses */
+  NVK_K_EXPECTED = 4,    /* expected-level gather */
+  NVK_K_CONSENSUS = 5,   /* normalise + strand flip + scatter-add */
+  NVK_K_POSTERIOR = 6,   /* windowed posterior */
+  NVK_K_COUNT = 7
+};
+
+const char *nvk_last_error(void); /* thread-local message of the last failing call */
+int nvk_device_count(void);       /* number of visible HIP devices (0 if none) */
+
+int nvk_ctx_create(int device, nvk_ctx **out);
+void nvk_ctx_destroy(nvk_ctx *ctx);
+int nvk_ctx_synchronize(nvk_ctx *ctx);
+void *nvk_ctx_stream(nvk_ctx *ctx); /* the hipStream_t all kernels of this ctx run on */
+/* number of reads processed concurrently by the sweep kernels (0 = automatic) */
+int nvk_ctx_set_slots(nvk_ctx *ctx, int slots);
+
+/* per-kernel HIP-event timing on the ctx stream (bench.py's roofline leg) */
+int nvk_timing_enable(nvk_ctx *ctx, int on);
+int nvk_timing_reset(nvk_ctx *ctx);
+int nvk_timing_read(nvk_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches);
+/* counters of the last batch call: total band cells C = sum_r W_r,
+ * wavefront steps, and the workspace bytes the sweep kernels streamed */
+int nvk_last_batch_stats(nvk_ctx *ctx, int64_t *band_cells, int64_t *wave_steps,
+                         int64_t *spill_bytes);
+
+/* replaces dtw.KmerModel(k, central_position, alphabet_size, mean, sigma)
+ * (dtwmodule.cpp:12-13, kmer_model.cpp:6-14).  mean/sigma: host f64[n], n = alphabet^k */
+int nvk_model_create(nvk_ctx *ctx, int k, int central_position, int alphabet_size,
+                     const double *mean, const double *sigma, int64_t n, nvk_model **out);
+void nvk_model_destroy(nvk_model *model);
+/* replaces KmerModel.get_k / get_central_position (dtwmodule.cpp:14-15) */
+int nvk_model_info(const nvk_model *model, int *k, int *central_position, int *alphabet_size);
+
+/* replaces KmerModel.get_expected_signal(reference, context_before, context_after)
+ * (dtwmodule.cpp:16-18, kmer_model.cpp:32-42), batched.  out: f64[ref_off[n]] */
+int nvk_expected_signal_batch(nvk_model *model, int64_t n_reads, const int32_t *reference,
+                              const int64_t *ref_off, const int32_t *ctx_before,
+                              const int64_t *cb_off, const int32_t *ctx_after,
+                              const int64_t *ca_off, double *out);
+int nvk_expected_signal_batch_dev(nvk_model *model, int64_t n_reads, int64_t total_ref,
+                                  const int32_t *reference, const int64_t *ref_off,
+                                  const int32_t *ctx_before, const int64_t *cb_off,
+                                  const int32_t *ctx_after, const int64_t *ca_off, double *out);
+
+/* replaces dtw.refine_alignment(signal, reference, context_before, context_after,
+ * approximate_alignment, bandwidth, min_event_length, kmer_model, model_transitions)
+ * (dtwmodule.cpp:24-28, dtw.cpp:133-228), batched.
+ *   out_events  i32[2*ref_off[n]]  (event_start, event_end) per base, slice coordinates
+ *   out_status  i32[n]             NVK_READ_*; for a read without a path its events are
+ *                                  left untouched (the reference returns an empty list) */
+int nvk_refine_alignment_batch(nvk_model *model, int64_t n_reads, const double *signal,
+                               const int64_t *sig_off, const int32_t *reference,
+                               const int64_t *ref_off, const int32_t *ctx_before,
+                               const int64_t *cb_off, const int32_t *ctx_after,
+                               const int64_t *ca_off, const int32_t *anchors,
+                               const int64_t *anc_off, int bandwidth, int min_event_length,
+                               int model_transitions, int32_t *out_events, int32_t *out_status);
+/* device-pointer flavour: total_* are the host-known last entries of the offset arrays */
+int nvk_refine_alignment_batch_dev(nvk_model *model, int64_t n_reads, int64_t total_signal,
+                                   int64_t total_ref, int64_t total_anchors, const double *signal,
+                                   const int64_t *sig_off, const int32_t *reference,
+                                   const int64_t *ref_off, const int32_t *ctx_before,
+                                   const int64_t *cb_off, const int32_t *ctx_after,
+                                   const int64_t *ca_off, const int32_t *anchors,
+                                   const int64_t *anc_off, int bandwidth, int min_event_length,
+                                   int model_transitions, int32_t *out_events,
+                                   int32_t *out_status);
+
+/* replaces dtw.estimate_log_likelihoods(signal, reference, context_before, context_after,
+ * approximate_alignment, bandwidth, min_event_length, kmer_model, model_wobbling)
+ * (dtwmodule.cpp:19-23, dtw.cpp:37-131), batched.
+ *   out_ll      f64[alphabet*ref_off[n]]  row-major (base position, substituted base)
+ *   out_status  i32[n] */
+int nvk_estimate_log_likelihoods_batch(nvk_model *model, int64_t n_reads, const double *signal,
+                                       const int64_t *sig_off, const int32_t *reference,
+                                       const int64_t *ref_off, const int32_t *ctx_before,
+                                       const int64_t *cb_off, const int32_t *ctx_after,
+                                       const int64_t *ca_off, const int32_t *anchors,
+                                       const int64_t *anc_off, int bandwidth,
+                                       int min_event_length, int model_wobbling, double *out_ll,
+                                       int32_t *out_status);
+int nvk_estimate_log_likelihoods_batch_dev(
+    nvk_model *model, int64_t n_reads, int64_t total_signal, int64_t total_ref,
+    int64_t total_anchors, const double *signal, const int64_t *sig_off,
+    const int32_t *reference, const int64_t *ref_off, const int32_t *ctx_before,
+    const int64_t *cb_off, const int32_t *ctx_after, const int64_t *ca_off,
+    const int32_t *anchors, const int64_t *anc_off, int bandwidth, int min_event_length,
+    int model_wobbling, double *out_ll, int32_t *out_status);
+
+/* replaces the Chunk score accumulation of ProbabilityEstimator
+ * (/root/reference/nadavca/estimator.py:45-47,112-119,226-231): for every read j,
+ *   ll' = (ll - ll[0][reference[0]]) / normalization_event_length,
+ *   reverse strand: column b -> alphabet-1-b and rows flipped,
+ *   acc[chunk_start[j] + p][b] += ll'[p][b],  coverage[chunk_start[j] + p] += 1.
+ * ll/reference/ref_off as produced by nvk_estimate_log_likelihoods_batch(_dev).
+ * Reads with status != 0 are skipped.  All pointers are device pointers; acc f64
+ * [ref_len*alphabet] and coverage i64[ref_len] are accumulated into (not zeroed). */
+int nvk_consensus_accumulate_dev(nvk_ctx *ctx, int64_t n_reads, int64_t total_ref, int alphabet,
+                                 const double *ll, const int32_t *reference,
+                                 const int64_t *ref_off, const int64_t *chunk_start,
+                                 const int32_t *reverse, const int32_t *status,
+                                 double normalization_event_length, int64_t ref_len, double *acc,
+                                 int64_t *coverage);
+
+/* replaces ProbabilityEstimator._compute_posterior / _corrected_priors
+ * (estimator.py:123-156) for one group of `len` consecutive positions.
+ * ll f64[len*alphabet], reference i32[len] (numerical bases), out f64[len*alphabet];
+ * device pointers. */
+int nvk_posterior_dev(nvk_ctx *ctx, int64_t len, int alphabet, int k, double snp_prior,
+                      const double *ll, const int32_t *reference, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NADAVCA_HIP_H */

@@ -1,0 +1,158 @@
+"""ctypes binding of nadavca_amd/csrc/libnadavca_hip.so (ABI: include/nadavca_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C nadavca_amd/csrc``.
+There is no fallback: a missing library or a missing GPU raises.
+"""
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libnadavca_hip.so')
+
+NVK_OK = 0
+NVK_ERR_NO_DEVICE = -1
+NVK_ERR_INVALID = -2
+NVK_ERR_HIP = -3
+NVK_ERR_UNSUPPORTED = -4
+NVK_ERR_NOMEM = -5
+
+READ_OK = 0
+READ_NO_PATH = 1
+READ_BAD_INPUT = -1
+READ_BAD_BAND = -2
+
+K_PLAN, K_ALIGN, K_ELL_SWEEP, K_ELL_HYP, K_EXPECTED, K_CONSENSUS, K_POSTERIOR = range(7)
+KERNEL_NAMES = ['plan', 'align', 'ell_sweep', 'ell_hyp', 'expected', 'consensus', 'posterior']
+
+_vp = C.c_void_p
+_i64 = C.c_int64
+_int = C.c_int
+_dbl = C.c_double
+
+# every symbol include/nadavca_hip.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    'nvk_last_error': (C.c_char_p, []),
+    'nvk_device_count': (_int, []),
+    'nvk_ctx_create': (_int, [_int, C.POINTER(_vp)]),
+    'nvk_ctx_destroy': (None, [_vp]),
+    'nvk_ctx_synchronize': (_int, [_vp]),
+    'nvk_ctx_stream': (_vp, [_vp]),
+    'nvk_ctx_set_slots': (_int, [_vp, _int]),
+    'nvk_timing_enable': (_int, [_vp, _int]),
+    'nvk_timing_reset': (_int, [_vp]),
+    'nvk_timing_read': (_int, [_vp, _int, C.POINTER(_dbl), C.POINTER(_i64)]),
+    'nvk_last_batch_stats': (_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
+    'nvk_model_create': (_int, [_vp, _int, _int, _int, _vp, _vp, _i64, C.POINTER(_vp)]),
+    'nvk_model_destroy': (None, [_vp]),
+    'nvk_model_info': (_int, [_vp, C.POINTER(_int), C.POINTER(_int), C.POINTER(_int)]),
+    'nvk_expected_signal_batch': (_int, [_vp, _i64] + [_vp] * 7),
+    'nvk_expected_signal_batch_dev': (_int, [_vp, _i64, _i64] + [_vp] * 7),
+    'nvk_refine_alignment_batch': (_int, [_vp, _i64] + [_vp] * 10 + [_int, _int, _int, _vp, _vp]),
+    'nvk_refine_alignment_batch_dev': (_int, [_vp, _i64, _i64, _i64, _i64] + [_vp] * 10 + [_int, _int, _int, _vp, _vp]),
+    'nvk_estimate_log_likelihoods_batch': (_int, [_vp, _i64] + [_vp] * 10 + [_int, _int, _int, _vp, _vp]),
+    'nvk_estimate_log_likelihoods_batch_dev': (_int, [_vp, _i64, _i64, _i64, _i64] + [_vp] * 10 + [_int, _int, _int, _vp, _vp]),
+    'nvk_consensus_accumulate_dev': (_int, [_vp, _i64, _i64, _int] + [_vp] * 6 + [_dbl, _i64, _vp, _vp]),
+    'nvk_posterior_dev': (_int, [_vp, _i64, _int, _int, _dbl, _vp, _vp, _vp]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class NadavcaHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libnadavca_hip.so (once) and attach the prototypes.  Raises if it is missing."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.isfile(LIB_PATH):
+            raise NadavcaHipError(
+                'HIP library not built: %s is missing (run __graft_entry__.build() or '
+                '`make -C nadavca_amd/csrc`). There is no CPU fallback.' % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+def check(rc, what):
+    if rc != NVK_OK:
+        lib = load()
+        msg = lib.nvk_last_error()
+        msg = msg.decode('utf-8', 'replace') if msg else ''
+        if rc == NVK_ERR_INVALID:
+            raise ValueError('%s: %s' % (what, msg))
+        raise NadavcaHipError('%s failed (%d): %s' % (what, rc, msg))
+
+
+class Context:
+    """One per process/GPU: owns the HIP stream, the workspaces and the timers."""
+
+    def __init__(self, device=0):
+        lib = load()
+        self._lib = lib
+        h = _vp()
+        check(lib.nvk_ctx_create(int(device), C.byref(h)), 'nvk_ctx_create')
+        self.handle = h
+        self.device = int(device)
+
+    def synchronize(self):
+        check(self._lib.nvk_ctx_synchronize(self.handle), 'nvk_ctx_synchronize')
+
+    def set_slots(self, slots):
+        check(self._lib.nvk_ctx_set_slots(self.handle, int(slots)), 'nvk_ctx_set_slots')
+
+    def timing_enable(self, on=True):
+        check(self._lib.nvk_timing_enable(self.handle, int(bool(on))), 'nvk_timing_enable')
+
+    def timing_reset(self):
+        check(self._lib.nvk_timing_reset(self.handle), 'nvk_timing_reset')
+
+    def timing_read(self):
+        out = {}
+        for kid, name in enumerate(KERNEL_NAMES):
+            ms, n = _dbl(), _i64()
+            check(self._lib.nvk_timing_read(self.handle, kid, C.byref(ms), C.byref(n)), 'nvk_timing_read')
+            out[name] = (ms.value, n.value)
+        return out
+
+    def last_batch_stats(self):
+        a, b, c = _i64(), _i64(), _i64()
+        check(self._lib.nvk_last_batch_stats(self.handle, C.byref(a), C.byref(b), C.byref(c)),
+              'nvk_last_batch_stats')
+        return dict(band_cells=a.value, wave_steps=b.value, spill_bytes=c.value)
+
+    def close(self):
+        if getattr(self, 'handle', None):
+            self._lib.nvk_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = {}
+
+
+def default_context(device=None):
+    """Process-wide context for ``device`` (default: LOCAL_RANK or 0)."""
+    if device is None:
+        device = int(os.environ.get('LOCAL_RANK', '0'))
+        lib = load()
+        n = lib.nvk_device_count()
+        if n > 0:
+            device %= n
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]

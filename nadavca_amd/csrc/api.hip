@@ -1,0 +1,498 @@
+// C-ABI entry points of libnadavca_hip.so (declared in include/nadavca_hip.h).
+// Host-side orchestration only: argument checks, workspace management, kernel launches.
+// There is deliberately no CPU implementation of any operator in this library.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "nvk_internal.h"
+
+static thread_local char g_err[512] = "";
+
+void nvk_set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char *nvk_last_error(void) { return g_err; }
+
+extern "C" int nvk_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int nvk_ws_reserve(nvk_ctx *ctx, int which, size_t bytes) {
+  if (bytes <= ctx->ws_bytes[which]) return NVK_OK;
+  if (ctx->ws[which]) {
+    NVK_HIP(hipStreamSynchronize(ctx->stream));
+    NVK_HIP(hipFree(ctx->ws[which]));
+    ctx->ws[which] = nullptr;
+    ctx->ws_bytes[which] = 0;
+  }
+  size_t want = bytes + bytes / 8 + 4096;
+  hipError_t e = hipMalloc(&ctx->ws[which], want);
+  if (e != hipSuccess) {
+    want = bytes;
+    e = hipMalloc(&ctx->ws[which], want);
+  }
+  if (e != hipSuccess) {
+    nvk_set_error("hipMalloc of %zu bytes failed: %s", want, hipGetErrorString(e));
+    ctx->ws[which] = nullptr;
+    return NVK_ERR_NOMEM;
+  }
+  ctx->ws_bytes[which] = want;
+  return NVK_OK;
+}
+
+TimerScope::TimerScope(nvk_ctx *c, int kid) : ctx(c), id(kid) {
+  if (ctx->timing_on) (void)hipEventRecord(ctx->ev0, ctx->stream);
+}
+TimerScope::~TimerScope() {
+  if (ctx->timing_on) {
+    (void)hipEventRecord(ctx->ev1, ctx->stream);
+    (void)hipEventSynchronize(ctx->ev1);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) {
+      ctx->k_ms[id] += (double)ms;
+      ctx->k_launches[id] += 1;
+    }
+  }
+}
+
+extern "C" int nvk_ctx_create(int device, nvk_ctx **out) {
+  if (!out) {
+    nvk_set_error("nvk_ctx_create: out is NULL");
+    return NVK_ERR_INVALID;
+  }
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+    nvk_set_error("no HIP device visible (this library has no CPU fallback)");
+    return NVK_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= n) {
+    nvk_set_error("device %d out of range (0..%d)", device, n - 1);
+    return NVK_ERR_INVALID;
+  }
+  NVK_HIP(hipSetDevice(device));
+  nvk_ctx *c = new nvk_ctx();
+  memset(c, 0, sizeof *c);
+  c->device = device;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
+    delete c;
+    nvk_set_error("hipGetDeviceProperties failed");
+    return NVK_ERR_HIP;
+  }
+  c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (hipStreamCreate(&c->stream) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
+      hipEventCreate(&c->ev1) != hipSuccess) {
+    delete c;
+    nvk_set_error("stream/event creation failed");
+    return NVK_ERR_HIP;
+  }
+  *out = c;
+  return NVK_OK;
+}
+
+extern "C" void nvk_ctx_destroy(nvk_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (int i = 0; i < 8; i++)
+    if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
+  (void)hipEventDestroy(ctx->ev0);
+  (void)hipEventDestroy(ctx->ev1);
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+extern "C" int nvk_ctx_synchronize(nvk_ctx *ctx) {
+  if (!ctx) return NVK_ERR_INVALID;
+  NVK_HIP(hipStreamSynchronize(ctx->stream));
+  return NVK_OK;
+}
+
+extern "C" void *nvk_ctx_stream(nvk_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+extern "C" int nvk_ctx_set_slots(nvk_ctx *ctx, int slots) {
+  if (!ctx || slots < 0) return NVK_ERR_INVALID;
+  ctx->slots_override = slots;
+  return NVK_OK;
+}
+
+extern "C" int nvk_timing_enable(nvk_ctx *ctx, int on) {
+  if (!ctx) return NVK_ERR_INVALID;
+  ctx->timing_on = on ? 1 : 0;
+  return NVK_OK;
+}
+
+extern "C" int nvk_timing_reset(nvk_ctx *ctx) {
+  if (!ctx) return NVK_ERR_INVALID;
+  for (int i = 0; i < NVK_K_COUNT; i++) {
+    ctx->k_ms[i] = 0.0;
+    ctx->k_launches[i] = 0;
+  }
+  return NVK_OK;
+}
+
+extern "C" int nvk_timing_read(nvk_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches) {
+  if (!ctx || kernel_id < 0 || kernel_id >= NVK_K_COUNT) return NVK_ERR_INVALID;
+  if (total_ms) *total_ms = ctx->k_ms[kernel_id];
+  if (launches) *launches = ctx->k_launches[kernel_id];
+  return NVK_OK;
+}
+
+extern "C" int nvk_last_batch_stats(nvk_ctx *ctx, int64_t *band_cells, int64_t *wave_steps,
+                                    int64_t *spill_bytes) {
+  if (!ctx) return NVK_ERR_INVALID;
+  if (band_cells) *band_cells = ctx->last_cells;
+  if (wave_steps) *wave_steps = ctx->last_steps;
+  if (spill_bytes) *spill_bytes = ctx->last_spill_bytes;
+  return NVK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// model
+// ---------------------------------------------------------------------------------------------
+extern "C" int nvk_model_create(nvk_ctx *ctx, int k, int central_position, int alphabet_size,
+                                const double *mean, const double *sigma, int64_t n,
+                                nvk_model **out) {
+  if (!ctx || !out || !mean || !sigma) {
+    nvk_set_error("nvk_model_create: NULL argument");
+    return NVK_ERR_INVALID;
+  }
+  *out = nullptr;
+  if (k < 1 || k > 15 || alphabet_size < 2 || alphabet_size > 8 || central_position < 0 ||
+      central_position >= k) {
+    nvk_set_error("nvk_model_create: unsupported shape k=%d central=%d alphabet=%d", k,
+                  central_position, alphabet_size);
+    return NVK_ERR_INVALID;
+  }
+  int64_t want = 1;
+  for (int i = 0; i < k; i++) want *= alphabet_size;
+  if (n != want) {
+    nvk_set_error("nvk_model_create: table has %lld rows, alphabet^k = %lld", (long long)n,
+                  (long long)want);
+    return NVK_ERR_INVALID;
+  }
+  NVK_HIP(hipSetDevice(ctx->device));
+  // additive / multiplicative constants exactly as kmer_model.cpp:9-12 spells them
+  std::vector<double> ac((size_t)n), mc((size_t)n);
+  for (int64_t i = 0; i < n; i++) {
+    double s = sigma[i];
+    ac[(size_t)i] = log(1 / sqrt(2 * M_PI * s * s));
+    mc[(size_t)i] = 1 / (2 * s * s);
+  }
+  nvk_model *m = new nvk_model();
+  memset(m, 0, sizeof *m);
+  m->ctx = ctx;
+  size_t bytes = (size_t)n * sizeof(double);
+  if (hipMalloc((void **)&m->d_mean, bytes) != hipSuccess ||
+      hipMalloc((void **)&m->d_ac, bytes) != hipSuccess ||
+      hipMalloc((void **)&m->d_mc, bytes) != hipSuccess) {
+    nvk_set_error("nvk_model_create: hipMalloc failed");
+    nvk_model_destroy(m);
+    return NVK_ERR_NOMEM;
+  }
+  NVK_HIP(hipMemcpy(m->d_mean, mean, bytes, hipMemcpyHostToDevice));
+  NVK_HIP(hipMemcpy(m->d_ac, ac.data(), bytes, hipMemcpyHostToDevice));
+  NVK_HIP(hipMemcpy(m->d_mc, mc.data(), bytes, hipMemcpyHostToDevice));
+  m->dm.k = k;
+  m->dm.central = central_position;
+  m->dm.alphabet = alphabet_size;
+  m->dm.n = n;
+  m->dm.mean = m->d_mean;
+  m->dm.ac = m->d_ac;
+  m->dm.mc = m->d_mc;
+  *out = m;
+  return NVK_OK;
+}
+
+extern "C" void nvk_model_destroy(nvk_model *m) {
+  if (!m) return;
+  if (m->d_mean) (void)hipFree(m->d_mean);
+  if (m->d_ac) (void)hipFree(m->d_ac);
+  if (m->d_mc) (void)hipFree(m->d_mc);
+  delete m;
+}
+
+extern "C" int nvk_model_info(const nvk_model *m, int *k, int *central_position,
+                              int *alphabet_size) {
+  if (!m) return NVK_ERR_INVALID;
+  if (k) *k = m->dm.k;
+  if (central_position) *central_position = m->dm.central;
+  if (alphabet_size) *alphabet_size = m->dm.alphabet;
+  return NVK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// helpers for the host-pointer flavours
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct DevBuf {
+  void *p = nullptr;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+  int alloc(size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+      nvk_set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+      return NVK_ERR_NOMEM;
+    }
+    return NVK_OK;
+  }
+  int upload(const void *src, size_t bytes, hipStream_t s) {
+    int rc = alloc(bytes);
+    if (rc) return rc;
+    if (bytes) NVK_HIP(hipMemcpyAsync(p, src, bytes, hipMemcpyHostToDevice, s));
+    return NVK_OK;
+  }
+};
+
+int check_offsets(const char *what, const int64_t *off, int64_t n) {
+  if (!off) {
+    nvk_set_error("%s offsets are NULL", what);
+    return NVK_ERR_INVALID;
+  }
+  if (off[0] != 0) {
+    nvk_set_error("%s offsets must start at 0", what);
+    return NVK_ERR_INVALID;
+  }
+  for (int64_t i = 0; i < n; i++)
+    if (off[i + 1] < off[i]) {
+      nvk_set_error("%s offsets decrease at read %lld", what, (long long)i);
+      return NVK_ERR_INVALID;
+    }
+  return NVK_OK;
+}
+
+struct StagedBatch {
+  DevBuf signal, sig_off, ref, ref_off, cb, cb_off, ca, ca_off, anc, anc_off;
+  BatchArgs a;
+};
+
+int stage_batch(nvk_ctx *ctx, int64_t n, const double *signal, const int64_t *sig_off,
+                const int32_t *ref, const int64_t *ref_off, const int32_t *cb,
+                const int64_t *cb_off, const int32_t *ca, const int64_t *ca_off,
+                const int32_t *anc, const int64_t *anc_off, int bandwidth, int mel,
+                bool with_signal, StagedBatch &sb) {
+  int rc;
+  if ((rc = check_offsets("reference", ref_off, n))) return rc;
+  if ((rc = check_offsets("context_before", cb_off, n))) return rc;
+  if ((rc = check_offsets("context_after", ca_off, n))) return rc;
+  if (with_signal) {
+    if ((rc = check_offsets("signal", sig_off, n))) return rc;
+    if ((rc = check_offsets("anchors", anc_off, n))) return rc;
+  }
+  hipStream_t s = ctx->stream;
+  size_t no = (size_t)(n + 1) * sizeof(int64_t);
+  BatchArgs &a = sb.a;
+  memset(&a, 0, sizeof a);
+  a.n_reads = n;
+  a.total_ref = ref_off[n];
+  a.bandwidth = bandwidth;
+  a.mel = mel;
+  if ((rc = sb.ref.upload(ref, (size_t)ref_off[n] * 4, s))) return rc;
+  if ((rc = sb.ref_off.upload(ref_off, no, s))) return rc;
+  if ((rc = sb.cb.upload(cb, (size_t)cb_off[n] * 4, s))) return rc;
+  if ((rc = sb.cb_off.upload(cb_off, no, s))) return rc;
+  if ((rc = sb.ca.upload(ca, (size_t)ca_off[n] * 4, s))) return rc;
+  if ((rc = sb.ca_off.upload(ca_off, no, s))) return rc;
+  a.reference = (const int32_t *)sb.ref.p;
+  a.ref_off = (const int64_t *)sb.ref_off.p;
+  a.ctx_before = (const int32_t *)sb.cb.p;
+  a.cb_off = (const int64_t *)sb.cb_off.p;
+  a.ctx_after = (const int32_t *)sb.ca.p;
+  a.ca_off = (const int64_t *)sb.ca_off.p;
+  if (with_signal) {
+    a.total_signal = sig_off[n];
+    a.total_anchors = anc_off[n];
+    if ((rc = sb.signal.upload(signal, (size_t)sig_off[n] * 8, s))) return rc;
+    if ((rc = sb.sig_off.upload(sig_off, no, s))) return rc;
+    if ((rc = sb.anc.upload(anc, (size_t)anc_off[n] * 8, s))) return rc;
+    if ((rc = sb.anc_off.upload(anc_off, no, s))) return rc;
+    a.signal = (const double *)sb.signal.p;
+    a.sig_off = (const int64_t *)sb.sig_off.p;
+    a.anchors = (const int32_t *)sb.anc.p;
+    a.anc_off = (const int64_t *)sb.anc_off.p;
+  }
+  return NVK_OK;
+}
+
+int check_common(nvk_model *model, int64_t n_reads, int bandwidth, int mel) {
+  if (!model) {
+    nvk_set_error("model handle is NULL");
+    return NVK_ERR_INVALID;
+  }
+  if (n_reads < 0 || n_reads > 0x7fffffff) {
+    nvk_set_error("n_reads %lld out of range", (long long)n_reads);
+    return NVK_ERR_INVALID;
+  }
+  if (bandwidth < 0 || bandwidth > (1 << 28)) {
+    nvk_set_error("bandwidth %d out of range", bandwidth);
+    return NVK_ERR_INVALID;
+  }
+  if (mel < 0) {
+    nvk_set_error("min_event_length %d is negative", mel);
+    return NVK_ERR_INVALID;
+  }
+  return NVK_OK;
+}
+
+// plan a batch: metas + row table in ctx workspaces, totals read back to the host
+int plan_batch(nvk_model *model, const BatchArgs &a, int mode, int wobbling, PlanTotals &tot) {
+  nvk_ctx *ctx = model->ctx;
+  int64_t n = a.n_reads;
+  int64_t rows_total = (mode == PLAN_ALIGN_TRANS) ? 2 * a.total_ref : a.total_ref + n;
+  int rc;
+  if ((rc = nvk_ws_reserve(ctx, WS_META, (size_t)(n + 1) * sizeof(ReadMeta) + 64))) return rc;
+  if ((rc = nvk_ws_reserve(ctx, WS_ROWS, (size_t)(rows_total + 1) * sizeof(RowParam)))) return rc;
+  if ((rc = nvk_ws_reserve(ctx, WS_BANDTMP, (size_t)(2 * (a.total_ref + n) + 2) * 8))) return rc;
+  if ((rc = nvk_ws_reserve(ctx, WS_MISC, 256))) return rc;
+  PlanTotals *d_tot = (PlanTotals *)((char *)ctx->ws[WS_MISC] + 64);
+  rc = launch_plan(ctx, model->dm, a, mode, wobbling, (ReadMeta *)ctx->ws[WS_META],
+                   (RowParam *)ctx->ws[WS_ROWS], (unsigned long long *)ctx->ws[WS_BANDTMP], d_tot);
+  if (rc) return rc;
+  NVK_HIP(hipMemcpyAsync(&tot, d_tot, sizeof(PlanTotals), hipMemcpyDeviceToHost, ctx->stream));
+  NVK_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->last_cells = (int64_t)tot.cells;
+  ctx->last_steps = (int64_t)tot.steps;
+  return NVK_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// expected signal
+// ---------------------------------------------------------------------------------------------
+extern "C" int nvk_expected_signal_batch_dev(nvk_model *model, int64_t n_reads, int64_t total_ref,
+                                             const int32_t *reference, const int64_t *ref_off,
+                                             const int32_t *ctx_before, const int64_t *cb_off,
+                                             const int32_t *ctx_after, const int64_t *ca_off,
+                                             double *out) {
+  int rc = check_common(model, n_reads, 0, 0);
+  if (rc) return rc;
+  nvk_ctx *ctx = model->ctx;
+  NVK_HIP(hipSetDevice(ctx->device));
+  rc = launch_expected(ctx, model->dm, n_reads, total_ref, reference, ref_off, ctx_before, cb_off,
+                       ctx_after, ca_off, out);
+  if (rc) return rc;
+  NVK_HIP(hipStreamSynchronize(ctx->stream));
+  return NVK_OK;
+}
+
+extern "C" int nvk_expected_signal_batch(nvk_model *model, int64_t n_reads,
+                                         const int32_t *reference, const int64_t *ref_off,
+                                         const int32_t *ctx_before, const int64_t *cb_off,
+                                         const int32_t *ctx_after, const int64_t *ca_off,
+                                         double *out) {
+  int rc = check_common(model, n_reads, 0, 0);
+  if (rc) return rc;
+  nvk_ctx *ctx = model->ctx;
+  NVK_HIP(hipSetDevice(ctx->device));
+  StagedBatch sb;
+  rc = stage_batch(ctx, n_reads, nullptr, nullptr, reference, ref_off, ctx_before, cb_off,
+                   ctx_after, ca_off, nullptr, nullptr, 0, 0, false, sb);
+  if (rc) return rc;
+  DevBuf d_out;
+  if ((rc = d_out.alloc((size_t)sb.a.total_ref * 8))) return rc;
+  rc = launch_expected(ctx, model->dm, n_reads, sb.a.total_ref, sb.a.reference, sb.a.ref_off,
+                       sb.a.ctx_before, sb.a.cb_off, sb.a.ctx_after, sb.a.ca_off, (double *)d_out.p);
+  if (rc) return rc;
+  if (sb.a.total_ref)
+    NVK_HIP(hipMemcpyAsync(out, d_out.p, (size_t)sb.a.total_ref * 8, hipMemcpyDeviceToHost,
+                           ctx->stream));
+  NVK_HIP(hipStreamSynchronize(ctx->stream));
+  return NVK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// refine_alignment
+// ---------------------------------------------------------------------------------------------
+extern "C" int nvk_refine_alignment_batch_dev(
+    nvk_model *model, int64_t n_reads, int64_t total_signal, int64_t total_ref,
+    int64_t total_anchors, const double *signal, const int64_t *sig_off, const int32_t *reference,
+    const int64_t *ref_off, const int32_t *ctx_before, const int64_t *cb_off,
+    const int32_t *ctx_after, const int64_t *ca_off, const int32_t *anchors,
+    const int64_t *anc_off, int bandwidth, int min_event_length, int model_transitions,
+    int32_t *out_events, int32_t *out_status) {
+  int rc = check_common(model, n_reads, bandwidth, min_event_length);
+  if (rc) return rc;
+  if (min_event_length > 4) {
+    nvk_set_error("min_event_length %d outside the compiled range 0..4", min_event_length);
+    return NVK_ERR_UNSUPPORTED;
+  }
+  nvk_ctx *ctx = model->ctx;
+  NVK_HIP(hipSetDevice(ctx->device));
+  if (n_reads == 0) return NVK_OK;
+  BatchArgs a;
+  memset(&a, 0, sizeof a);
+  a.n_reads = n_reads;
+  a.total_signal = total_signal;
+  a.total_ref = total_ref;
+  a.total_anchors = total_anchors;
+  a.signal = signal;
+  a.sig_off = sig_off;
+  a.reference = reference;
+  a.ref_off = ref_off;
+  a.ctx_before = ctx_before;
+  a.cb_off = cb_off;
+  a.ctx_after = ctx_after;
+  a.ca_off = ca_off;
+  a.anchors = anchors;
+  a.anc_off = anc_off;
+  a.bandwidth = bandwidth;
+  a.mel = min_event_length;
+  PlanTotals tot;
+  rc = plan_batch(model, a, model_transitions ? PLAN_ALIGN_TRANS : PLAN_ALIGN_PLAIN, 0, tot);
+  if (rc) return rc;
+  rc = launch_align(ctx, a, model_transitions ? 1 : 0, (const ReadMeta *)ctx->ws[WS_META],
+                    (const RowParam *)ctx->ws[WS_ROWS], tot, out_events, out_status);
+  if (rc) return rc;
+  NVK_HIP(hipStreamSynchronize(ctx->stream));
+  return NVK_OK;
+}
+
+extern "C" int nvk_refine_alignment_batch(nvk_model *model, int64_t n_reads, const double *signal,
+                                          const int64_t *sig_off, const int32_t *reference,
+                                          const int64_t *ref_off, const int32_t *ctx_before,
+                                          const int64_t *cb_off, const int32_t *ctx_after,
+                                          const int64_t *ca_off, const int32_t *anchors,
+                                          const int64_t *anc_off, int bandwidth,
+                                          int min_event_length, int model_transitions,
+                                          int32_t *out_events, int32_t *out_status) {
+  int rc = check_common(model, n_reads, bandwidth, min_event_length);
+  if (rc) return rc;
+  if (n_reads == 0) return NVK_OK;
+  nvk_ctx *ctx = model->ctx;
+  NVK_HIP(hipSetDevice(ctx->device));
+  StagedBatch sb;
+  rc = stage_batch(ctx, n_reads, signal, sig_off, reference, ref_off, ctx_before, cb_off, ctx_after,
+                   ca_off, anchors, anc_off, bandwidth, min_event_length, true, sb);
+  if (rc) return rc;
+  DevBuf d_ev, d_st;
+  size_t evb = (size_t)sb.a.total_ref * 2 * 4, stb = (size_t)n_reads * 4;
+  if ((rc = d_ev.alloc(evb))) return rc;
+  if ((rc = d_st.alloc(stb))) return rc;
+  NVK_HIP(hipMemsetAsync(d_ev.p, 0, evb ? evb : 16, ctx->stream));
+  rc = nvk_refine_alignment_batch_dev(
+      model, n_reads, sb.a.total_signal, sb.a.total_ref, sb.a.total_anchors, sb.a.signal,
+      sb.a.sig_off, sb.a.reference, sb.a.ref_off, sb.a.ctx_before, sb.a.cb_off, sb.a.ctx_after,
+      sb.a.ca_off, sb.a.anchors, sb.a.anc_off, bandwidth, min_event_length, model_transitions,
+      (int32_t *)d_ev.p, (int32_t *)d_st.p);
+  if (rc) return rc;
+  if (evb) NVK_HIP(hipMemcpyAsync(out_events, d_ev.p, evb, hipMemcpyDeviceToHost, ctx->stream));
+  NVK_HIP(hipMemcpyAsync(out_status, d_st.p, stb, hipMemcpyDeviceToHost, ctx->stream));
+  NVK_HIP(hipStreamSynchronize(ctx->stream));
+  return NVK_OK;
+}

@@ -1,0 +1,301 @@
+// Planner: per read, the band of every DP row, the per-row step densities gathered from
+// the k-mer table, the lane-occupancy intervals and the wavefront skew.  One wave per read.
+//
+// Reference behaviour restated here:
+//   bands                 nadavca/dtw/dtw.cpp:7-35   (ComputeBandStarts / ComputeBandEnds)
+//   row layout            nadavca/dtw/dtw.cpp:144-180 (transitions: 2R rows; else R+1)
+//   k-mer id / densities  nadavca/dtw/kmer_model.cpp:22-94, sequence.cpp:6-29
+// The expected-level gather (KmerModel::GetExpectedSignal, kmer_model.cpp:32-42) is the
+// last kernel in this file.
+#include "nvk_internal.h"
+
+namespace {
+
+__device__ __forceinline__ int seq_at(const int32_t *ref, int R, const int32_t *cb, int nb,
+                                      const int32_t *ca, int na, int idx) {
+  // ExtendedSequence::operator[] : context_before | reference | context_after, 0 outside
+  if (idx < 0) {
+    int j = idx + nb;
+    return j >= 0 ? cb[j] : 0;
+  }
+  if (idx < R) return ref[idx];
+  int j = idx - R;
+  return j < na ? ca[j] : 0;
+}
+
+__device__ __forceinline__ int64_t kmer_id(const DeviceModel &dm, const int32_t *ref, int R,
+                                           const int32_t *cb, int nb, const int32_t *ca, int na,
+                                           int pos) {
+  int64_t id = 0;
+  for (int j = pos - dm.central; j < pos - dm.central + dm.k; j++)
+    id = id * dm.alphabet + seq_at(ref, R, cb, nb, ca, na, j);
+  return id;
+}
+
+__device__ __forceinline__ int wave_scan_max(int v, int lane) {
+  for (int d = 1; d < 64; d <<= 1) {
+    int o = __shfl_up(v, d, 64);
+    if (lane >= d) v = max(v, o);
+  }
+  return v;
+}
+__device__ __forceinline__ int wave_scan_min_rev(int v, int lane) {
+  for (int d = 1; d < 64; d <<= 1) {
+    int o = __shfl_down(v, d, 64);
+    if (lane + d < 64) v = min(v, o);
+  }
+  return v;
+}
+__device__ __forceinline__ int wave_max(int v) {
+  for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d, 64));
+  return v;
+}
+__device__ __forceinline__ long long wave_sum(long long v) {
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+
+// bandtmp: per read 2*(R+1) u64 scratch words at bandtmp[2*(ref_off+j) ...]
+__global__ __launch_bounds__(64) void plan_kernel(DeviceModel dm, BatchArgs a, int mode,
+                                                  ReadMeta *metas, RowParam *rows,
+                                                  unsigned long long *bandtmp,
+                                                  PlanTotals *totals) {
+  const int rd = blockIdx.x;
+  const int lane = threadIdx.x;
+  if (rd >= a.n_reads) return;
+  const int64_t s0 = a.sig_off[rd], r0 = a.ref_off[rd], a0 = a.anc_off[rd];
+  const int64_t N64 = a.sig_off[rd + 1] - s0;
+  const int64_t R64 = a.ref_off[rd + 1] - r0;
+  const int64_t A64 = a.anc_off[rd + 1] - a0;
+  const int nb = (int)(a.cb_off[rd + 1] - a.cb_off[rd]);
+  const int na = (int)(a.ca_off[rd + 1] - a.ca_off[rd]);
+  const int32_t *ref = a.reference + r0;
+  const int32_t *cb = a.ctx_before + a.cb_off[rd];
+  const int32_t *ca = a.ctx_after + a.ca_off[rd];
+  const int32_t *anc = a.anchors + 2 * a0;
+  const int N = (int)N64, R = (int)R64, A = (int)A64;
+  const int bw = a.bandwidth, mel = a.mel;
+
+  ReadMeta m;
+  m.sig_off = s0;
+  m.ref_off = r0;
+  m.N = N;
+  m.R = R;
+  m.status = NVK_READ_OK;
+  m.pad = 0;
+  m.cells = 0;
+  int T;
+  if (mode == PLAN_ALIGN_TRANS) {
+    T = 2 * R;
+    m.row_off = 2 * r0;
+  } else {
+    T = R + 1;
+    m.row_off = r0 + rd;
+  }
+  m.T = T;
+  m.c = 1;
+  m.t_min = 0;
+  m.n_steps = 0;
+
+  int bad = (R < 1 || N < 1 || N64 > 0x3fffffff || R64 > 0x1fffffff) ? 1 : 0;
+  // anchors must name an existing band row (reference writes result[reference_index])
+  for (int j = lane; j < A && !bad; j += 64) {
+    int ri = anc[2 * j + 1];
+    if (ri < 0 || ri > R) bad = 1;
+  }
+  bad = __any(bad);
+  if (bad) {
+    m.status = NVK_READ_BAD_INPUT;
+    if (lane == 0) metas[rd] = m;
+    return;
+  }
+
+  // --- bands: "later anchor overwrites", then prefix-max / suffix-min -------------------------
+  // scratch word = (anchor ordinal + 1) << 32 | payload ; atomicMax keeps the last anchor
+  unsigned long long *tbs = bandtmp + 2 * (r0 + rd);
+  unsigned long long *tbe = tbs + (R + 1);
+  for (int j = lane; j <= R; j += 64) {
+    tbs[j] = 0ull;
+    tbe[j] = 0ull;
+  }
+  __syncthreads();
+  for (int j = lane; j < A; j += 64) {
+    int s = anc[2 * j], ri = anc[2 * j + 1];
+    long long lo = (long long)s - bw;
+    long long hi = (long long)s + bw;
+    unsigned int vbs = (unsigned int)(lo > 0 ? (lo > N ? N : lo) : 0);  // max(0, s - bw)
+    // min(N, s + bw); a negative value cannot be packed: clamp to -1 -> flagged as bad band
+    unsigned int vbe = (unsigned int)((hi < N ? (hi < -1 ? -1 : hi) : N) + 1);
+    unsigned long long tag = ((unsigned long long)(j + 1)) << 32;
+    atomicMax(&tbs[ri], tag | vbs);
+    atomicMax(&tbe[ri], tag | vbe);
+  }
+  __syncthreads();
+  // the row table stores bands as int32 inside RowParam; first write raw per-base bands into
+  // the scratch (low words), scanning in chunks of 64 with a carry
+  int carry = 0;
+  for (int base = 0; base <= R; base += 64) {
+    int j = base + lane;
+    int v = 0;
+    if (j <= R) {
+      unsigned long long w = tbs[j];
+      v = (w >> 32) ? (int)(unsigned int)(w & 0xffffffffu) : 0;
+    }
+    v = max(wave_scan_max(v, lane), carry);
+    carry = __shfl(v, 63, 64);
+    if (j <= R) tbs[j] = (unsigned long long)(unsigned int)v;
+  }
+  carry = N;
+  for (int base = (R / 64) * 64; base >= 0; base -= 64) {
+    int j = base + lane;
+    int v = N;
+    if (j <= R) {
+      unsigned long long w = tbe[j];
+      v = (w >> 32) ? (int)(unsigned int)(w & 0xffffffffu) - 1 : N;
+    } else {
+      v = 0x7fffffff;
+    }
+    v = min(wave_scan_min_rev(v, lane), carry);
+    carry = __shfl(v, 0, 64);
+    if (j <= R) tbe[j] = (unsigned long long)(unsigned int)v;
+  }
+  __syncthreads();
+
+  // --- row table -----------------------------------------------------------------------------
+  RowParam *rp = rows + m.row_off;
+  const double log_p_in = log(0.01);
+  int badband = 0;
+  long long cells = 0;
+  for (int r = lane; r < T; r += 64) {
+    RowParam p;
+    int bidx = (mode == PLAN_ALIGN_TRANS) ? (r + 1) / 2 : r;
+    p.bs = (int)(unsigned int)tbs[bidx];
+    p.be = (int)(unsigned int)tbe[bidx];
+    if (p.be < p.bs) badband = 1;
+    cells += (long long)(p.be - p.bs + 1);
+    p.lo = p.bs;
+    p.hi = p.be;
+    p.mean = 0.0;
+    p.ac = 0.0;
+    p.mc = 0.0;
+    p.mean2 = 0.0;
+    p.ac2 = 0.0;
+    p.mc2 = 0.0;
+    p.mel = 0;
+    p.kind = 0;
+    if (r + 1 < T) {
+      if (mode == PLAN_ALIGN_TRANS && (r & 1)) {
+        // transition step between base r/2 and r/2+1: constant log(0.01), -inf on equal means
+        int i = r / 2;
+        double m1 = dm.mean[kmer_id(dm, ref, R, cb, nb, ca, na, i)];
+        double m2 = dm.mean[kmer_id(dm, ref, R, cb, nb, ca, na, i + 1)];
+        p.ac = (m1 == m2) ? -INFINITY : log_p_in;
+        p.mel = 0;
+      } else {
+        int i = (mode == PLAN_ALIGN_TRANS) ? r / 2 : r;
+        int64_t id = kmer_id(dm, ref, R, cb, nb, ca, na, i);
+        p.mean = dm.mean[id];
+        p.ac = dm.ac[id];
+        p.mc = dm.mc[id];
+        p.mel = mel;
+      }
+    }
+    rp[r] = p;
+  }
+  badband = __any(badband);
+  cells = wave_sum(cells);
+  __syncthreads();
+
+  // --- occupancy intervals (band + warm-up + pre-roll) and skew ---------------------------------
+  // forward lane of row r runs i = lo_r .. be_r, reverse lane i = hi_r .. bs_r  (see kernels_align.hip)
+  int cneed = 1;
+  for (int r = lane; r < T; r += 64) {
+    int lo = rp[r].bs, hi = rp[r].be;
+    if (r > 0) {
+      int pm = rp[r - 1].mel;
+      lo = min(lo, rp[r - 1].bs + pm) - max(pm - 1, 0);
+    }
+    if (r + 1 < T) {
+      int pm = rp[r].mel;
+      hi = max(hi, rp[r + 1].be - pm) + max(pm - 1, 0);
+    }
+    rp[r].lo = lo;
+    rp[r].hi = hi;
+  }
+  __syncthreads();
+  for (int r = 64 + lane; r < T; r += 64) {
+    int d = rp[r - 64].hi - rp[r].lo;  // need 64*c > d
+    if (d >= 0) cneed = max(cneed, d / 64 + 1);
+  }
+  cneed = max(cneed, max(mel - 1, 1));
+  int c = wave_max(cneed);
+
+  if (lane == 0) {
+    int t_min = rp[0].lo;
+    int t_max = rp[T - 1].hi + c * (T - 1);
+    m.c = c;
+    m.t_min = t_min;
+    m.n_steps = t_max - t_min + 1;
+    m.cells = cells;
+    if (badband) m.status = NVK_READ_BAD_BAND;
+    metas[rd] = m;
+    if (!badband) {
+      atomicMax(&totals->max_steps, m.n_steps);
+      atomicMax(&totals->max_c, c);
+      atomicMax(&totals->max_T, T);
+      atomicAdd(&totals->cells, (unsigned long long)cells);
+      atomicAdd(&totals->steps, (unsigned long long)m.n_steps);
+    }
+  }
+}
+
+__global__ void expected_kernel(DeviceModel dm, int64_t n_reads, int64_t total_ref,
+                                const int32_t *reference, const int64_t *ref_off,
+                                const int32_t *cbs, const int64_t *cb_off, const int32_t *cas,
+                                const int64_t *ca_off, double *out) {
+  // one thread per base; the read is found by binary search over ref_off
+  int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= total_ref) return;
+  int64_t lo = 0, hi = n_reads;  // ref_off[lo] <= g < ref_off[hi]
+  while (hi - lo > 1) {
+    int64_t mid = (lo + hi) >> 1;
+    if (ref_off[mid] <= g) lo = mid; else hi = mid;
+  }
+  int64_t rd = lo;
+  int R = (int)(ref_off[rd + 1] - ref_off[rd]);
+  int nb = (int)(cb_off[rd + 1] - cb_off[rd]);
+  int na = (int)(ca_off[rd + 1] - ca_off[rd]);
+  int pos = (int)(g - ref_off[rd]);
+  int64_t id = kmer_id(dm, reference + ref_off[rd], R, cbs + cb_off[rd], nb, cas + ca_off[rd], na, pos);
+  out[g] = dm.mean[id];
+}
+
+}  // namespace
+
+int launch_plan(nvk_ctx *ctx, const DeviceModel &dm, const BatchArgs &a, int mode, int wobbling,
+                ReadMeta *metas, RowParam *rows, unsigned long long *bandtmp, PlanTotals *totals) {
+  (void)wobbling;
+  NVK_HIP(hipMemsetAsync(totals, 0, sizeof(PlanTotals), ctx->stream));
+  if (a.n_reads == 0) return NVK_OK;
+  {
+    TimerScope ts(ctx, NVK_K_PLAN);
+    hipLaunchKernelGGL(plan_kernel, dim3((unsigned)a.n_reads), dim3(64), 0, ctx->stream, dm, a, mode,
+                       metas, rows, bandtmp, totals);
+  }
+  NVK_HIP(hipGetLastError());
+  return NVK_OK;
+}
+
+int launch_expected(nvk_ctx *ctx, const DeviceModel &dm, int64_t n_reads, int64_t total_ref,
+                    const int32_t *reference, const int64_t *ref_off, const int32_t *cb,
+                    const int64_t *cb_off, const int32_t *ca, const int64_t *ca_off, double *out) {
+  if (total_ref == 0) return NVK_OK;
+  {
+    TimerScope ts(ctx, NVK_K_EXPECTED);
+    unsigned blocks = (unsigned)((total_ref + 255) / 256);
+    hipLaunchKernelGGL(expected_kernel, dim3(blocks), dim3(256), 0, ctx->stream, dm, n_reads,
+                       total_ref, reference, ref_off, cb, cb_off, ca, ca_off, out);
+  }
+  NVK_HIP(hipGetLastError());
+  return NVK_OK;
+}

@@ -1,0 +1,126 @@
+// Internal declarations shared by the HIP translation units of libnadavca_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/nadavca_hip.h"
+
+// ----- device-side tables ---------------------------------------------------------------
+// One entry per DP row r of a read.  A "row" is a boundary line of the banded matrix
+// (reference: one Node, nadavca/dtw/node.h:7-30); the density fields describe the STEP
+// r -> r+1 (reference: distributions[r] / min_event_lengths[r], dtw.cpp:161-180).
+// A constant density (transition rows, kmer_model.cpp:64-94) is stored as a Gaussian
+// with mc = 0 and ac = the constant.
+struct __attribute__((aligned(16))) RowParam {
+  double mean, ac, mc;     // step r -> r+1 : e(x) = ac - (x-mean)^2 * mc
+  double mean2, ac2, mc2;  // second component for mixture (wobble) steps
+  int32_t bs, be;          // band of row r, inclusive sample-boundary indices
+  int32_t lo, hi;          // lane occupancy of row r: band + warm-up/pre-roll on both sides
+  int32_t mel;             // min event length of step r -> r+1
+  int32_t kind;            // 0 gauss/const, 1 mixture
+};
+static_assert(sizeof(RowParam) == 80, "RowParam layout");
+
+struct ReadMeta {
+  int64_t sig_off;   // first sample of the read's signal slice
+  int64_t row_off;   // first RowParam of the read
+  int64_t ref_off;   // first base (output offset)
+  int32_t N;         // samples in the slice
+  int32_t R;         // bases
+  int32_t T;         // DP rows
+  int32_t c;         // wavefront skew: cell (r,i) is computed at step t = i + c*r
+  int32_t t_min;     // first step
+  int32_t n_steps;   // number of steps
+  int32_t status;    // NVK_READ_*
+  int32_t pad;
+  int64_t cells;     // sum of band widths (algorithmic cell count)
+};
+
+// totals reduced over a batch by the planner (read back once by the host)
+struct PlanTotals {
+  int32_t max_steps;
+  int32_t max_c;
+  int32_t max_T;
+  int32_t max_W;
+  unsigned long long cells;
+  unsigned long long steps;
+};
+
+struct DeviceModel {
+  int k, central, alphabet;
+  int64_t n;
+  const double *mean, *ac, *mc;  // device arrays [n]
+};
+
+// ----- host-side objects ------------------------------------------------------------------
+struct nvk_ctx {
+  int device;
+  hipStream_t stream;
+  int slots_override;
+  int num_cus;
+  // growable workspaces (device)
+  void *ws[8];
+  size_t ws_bytes[8];
+  // timing
+  int timing_on;
+  double k_ms[NVK_K_COUNT];
+  int64_t k_launches[NVK_K_COUNT];
+  hipEvent_t ev0, ev1;
+  // stats of the last batch
+  int64_t last_cells, last_steps, last_spill_bytes;
+};
+
+struct nvk_model {
+  nvk_ctx *ctx;
+  DeviceModel dm;
+  double *d_mean, *d_ac, *d_mc;
+};
+
+enum { WS_META = 0, WS_ROWS = 1, WS_BANDTMP = 2, WS_SPILL = 3, WS_BP = 4, WS_MISC = 5, WS_ROWS2 = 6, WS_STAGE = 7 };
+
+void nvk_set_error(const char *fmt, ...);
+int nvk_ws_reserve(nvk_ctx *ctx, int which, size_t bytes);
+
+struct TimerScope {
+  nvk_ctx *ctx;
+  int id;
+  TimerScope(nvk_ctx *c, int kid);
+  ~TimerScope();
+};
+
+#define NVK_HIP(call)                                                                  \
+  do {                                                                                 \
+    hipError_t _e = (call);                                                            \
+    if (_e != hipSuccess) {                                                            \
+      nvk_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__,   \
+                    __LINE__);                                                         \
+      return NVK_ERR_HIP;                                                              \
+    }                                                                                  \
+  } while (0)
+
+// ----- launchers (kernels_*.hip) ------------------------------------------------------------
+struct BatchArgs {
+  int64_t n_reads, total_signal, total_ref, total_anchors;
+  const double *signal;
+  const int64_t *sig_off;
+  const int32_t *reference;
+  const int64_t *ref_off;
+  const int32_t *ctx_before;
+  const int64_t *cb_off;
+  const int32_t *ctx_after;
+  const int64_t *ca_off;
+  const int32_t *anchors;
+  const int64_t *anc_off;
+  int bandwidth, mel;
+};
+
+enum { PLAN_ALIGN_TRANS = 0, PLAN_ALIGN_PLAIN = 1, PLAN_ELL = 2 };
+
+int launch_plan(nvk_ctx *ctx, const DeviceModel &dm, const BatchArgs &a, int mode, int wobbling,
+                ReadMeta *metas, RowParam *rows, unsigned long long *bandtmp, PlanTotals *totals);
+int launch_align(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadMeta *metas,
+                 const RowParam *rows, const PlanTotals &tot, int32_t *out_events,
+                 int32_t *out_status);
+int launch_expected(nvk_ctx *ctx, const DeviceModel &dm, int64_t n_reads, int64_t total_ref,
+                    const int32_t *reference, const int64_t *ref_off, const int32_t *cb,
+                    const int64_t *cb_off, const int32_t *ca, const int64_t *ca_off, double *out);
