@@ -1,66 +1,66 @@
-// refine_alignment on gfx950: banded forward-backward in the log semiring + max-product path
-// search + traceback, one wave64 per read (persistent waves pull reads from a counter).
+// refine_alignment on gfx950: banded forward-backward + max-product path search + traceback,
+// one wave64 per read (persistent waves pull reads from a counter).
 //
 // What is computed (reference: nadavca/dtw/dtw.cpp:133-228, node_next_row.h:6-61,
 // node.cpp:39-91; exact semantics in SURVEY.md Appendix A.2/A.4):
-//   suffix[r][i], prefix[r][i]  banded sum-product rows, recurrence
-//        out[i] = (sum_{j<mel} e(s[i-1-j]) + pred[i-mel])  (+)  (e(s[i-1]) + out[i-1])
-//   post = prefix + suffix ; dp[r][i] = post[r][i] + max_{j <= i-mel} dp[r-1][j]  (first max wins)
+//   suffix[r][i], prefix[r][i]  banded sum-product rows, recurrence (probabilities, not logs)
+//        out[i] = prod_{j<mel} e(s[i-1-j]) * pred[i-mel]  +  e(s[i-1]) * out[i-1]
+//   post = prefix * suffix ; dp[r][i] = post[r][i] * max_{j <= i-mel} dp[r-1][j]  (first max wins)
 //   traceback of the arg-max chain -> (event_start, event_end) per base.
 //
 // How it is mapped (this is not how the reference does it):
+//   * scaled linear semiring (xmath.h): every probability is mantissa * 2^exponent, so the
+//     recurrence is mul/ldexp/add/frexp; the reference's exp+log per cell is gone, the
+//     2^-53 absorption rule of its log-sum-exp is kept by the add itself.
 //   * systolic anti-diagonal wavefront: cell (r, i) is computed at step t = i + c*r by lane
 //     r mod 64.  Each lane walks along its row; the value it needs from row r-1 was produced
 //     by the neighbouring lane c+mel steps earlier and is passed through a small LDS ring.
 //     The first/last-cell sums of the reference (all predecessors beyond the band edge) are
 //     obtained by starting the lane's recurrence early ("warm-up") — same mathematics.
 //   * the reverse sweep runs first and spills suffix[][] to HBM in (t, lane) order, so every
-//     step is one coalesced 512-byte store; the forward sweep re-reads it in the same order.
+//     step is one coalesced store; the forward sweep re-reads it in the same order.
 //   * back-pointers are not stored per cell: the path DP only needs, per (row, i), whether the
 //     running maximum was replaced at that cell — one bit, packed 32 steps per lane word.
 //   * signal samples and the row table are staged through LDS rings (coalesced refills).
 #include <math.h>
 
 #include "nvk_internal.h"
+#include "xmath.h"
 
 namespace {
 
-constexpr int CH = 128;      // signal refill chunk (samples)
-constexpr int TABN = 128;    // row-table window (two 64-row blocks)
-constexpr int PF = 8;        // forward sweep: spill prefetch depth (steps)
+using xm::X;
+
+constexpr int CH = 128;    // signal refill chunk (samples)
+constexpr int TABN = 128;  // row-table window (two 64-row blocks)
+constexpr int PF = 4;      // forward sweep: spill prefetch depth (steps)
 
 // One wave per workgroup: LDS traffic of a wave is executed in program order, so ordering
 // between lanes only needs the compiler not to reorder the accesses.  (__syncthreads() would
 // also drain vmcnt, i.e. wait for the spill stores of every step.)
-#define WAVE_SYNC()                                          \
-  do {                                                       \
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   \
-    __builtin_amdgcn_wave_barrier();                         \
+#define WAVE_SYNC()                                        \
+  do {                                                     \
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); \
+    __builtin_amdgcn_wave_barrier();                       \
   } while (0)
 
 struct AlignArgs {
   const ReadMeta *metas;
   const RowParam *rows;
   const double *signal;
-  double *spill;
-  uint32_t *bp;
-  int64_t spill_stride;  // doubles per slot
+  double *spill_m;   // suffix mantissas, [slot][step][lane]
+  int32_t *spill_e;  // suffix exponents
+  uint32_t *bp;      // path update bits, [slot][step/32][lane]
+  int64_t spill_stride;  // cells per slot
   int64_t bp_stride;     // words per slot
   int n_reads;
   int *counter;
-  int H;   // history ring slots (pow2 > c + mel)
+  int H;   // history ring slots (> c + mel; need not be a power of two)
   int SR;  // signal ring samples (pow2 >= 64*c + CH)
   int transitions;
   int32_t *out_events;
   int32_t *out_status;
 };
-
-__device__ __forceinline__ double lse2(double a, double b) {
-  // probability.cpp:33-40 : a (+) b = max + log(1 + exp(min - max)); -inf absorbs
-  double mx = fmax(a, b), mn = fmin(a, b);
-  double r = mx + log(1.0 + exp(mn - mx));
-  return (mn == -INFINITY) ? mx : r;
-}
 
 __device__ __forceinline__ void load_tab_block(RowParam *tab, const RowParam *rows, int blk, int T,
                                                int lane) {
@@ -68,20 +68,40 @@ __device__ __forceinline__ void load_tab_block(RowParam *tab, const RowParam *ro
   if (r >= 0 && r < T) tab[r & (TABN - 1)] = rows[r];
 }
 
+// e(x) of one step as an extended number; constant rows have mc == 0.  ac2/mc2 are the
+// reference's additive/multiplicative constants (kmer_model.cpp:9-12,48-50) times log2(e).
+__device__ __forceinline__ X density(double x, double mean, double ac2, double mc2) {
+  double d = x - mean;
+  return xm::from_log2(ac2 - d * d * mc2);
+}
+
+template <int MEL>
+__device__ __forceinline__ X emission_product(X e, X e1, X e2, X e3, int melr) {
+  // prod of the last mel densities, multiplied in the reference's order (newest first)
+  X P = xm::one();
+  if (MEL >= 1) P = e;
+  if (MEL >= 2) P = xm::mul(P, e1);
+  if (MEL >= 3) P = xm::mul(P, e2);
+  if (MEL >= 4) P = xm::mul(P, e3);
+  return xm::sel(melr == 0, xm::one(), P);
+}
+
 template <int MEL>
 __global__ __launch_bounds__(64) void align_kernel(AlignArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double *ring = reinterpret_cast<double *>(smem);
   RowParam *tab = reinterpret_cast<RowParam *>(ring + g.SR);
-  double *hist = reinterpret_cast<double *>(tab + TABN);
-  double *dhist = hist + (size_t)g.H * 64;
-  int *s_read = reinterpret_cast<int *>(dhist + (size_t)g.H * 64);
+  double *hist_m = reinterpret_cast<double *>(tab + TABN);
+  double *dhist_m = hist_m + (size_t)g.H * 64;
+  int *hist_e = reinterpret_cast<int *>(dhist_m + (size_t)g.H * 64);
+  int *dhist_e = hist_e + (size_t)g.H * 64;
+  int *s_read = dhist_e + (size_t)g.H * 64;
 
   const int lane = threadIdx.x;
-  const int HM = g.H - 1, RM = g.SR - 1;
-  double *spill = g.spill + (size_t)blockIdx.x * g.spill_stride;
+  const int H = g.H, RM = g.SR - 1;
+  double *spill_m = g.spill_m + (size_t)blockIdx.x * g.spill_stride;
+  int32_t *spill_e = g.spill_e + (size_t)blockIdx.x * g.spill_stride;
   uint32_t *bp = g.bp + (size_t)blockIdx.x * g.bp_stride;
-  const double NEG = -INFINITY;
 
   for (int q = lane; q < g.SR; q += 64) ring[q] = 0.0;
 
@@ -105,6 +125,10 @@ __global__ __launch_bounds__(64) void align_kernel(AlignArgs g) {
     const RowParam *rows = g.rows + m.row_off;
     const double *sig = g.signal + m.sig_off;
     const int top = T - 1;
+    int K = 0;  // exponent of the largest suffix[0][.]: posteriors are scaled by 2^-K
+    // history ring slots advance uniformly: slot written at step u is u mod H; a lane whose
+    // step needs mel samples reads the neighbour's slot from c+mel steps ago
+    const int sA0 = ((-c - MEL) % H + H) % H, sB0 = ((-c) % H + H) % H;
 
     // =========================== reverse sweep: suffix rows -> spill ===========================
     {
@@ -116,13 +140,12 @@ __global__ __launch_bounds__(64) void align_kernel(AlignArgs g) {
         load_tab_block(tab, rows, loaded_lo, T, lane);
       }
       __syncthreads();
-      // lane state
-      double mean = 0, ac = 0, mc = 0;
-      int bs = 0, hi = -1, pbs = 0, pbe = -1, melr = 0;
+      double mean = 0, ac2 = 0, mc2 = 0;
+      int bs = 0x40000000, hi = -0x40000000, pbs = 0, pbe = -1, melr = 0;
       bool is_init = false;
       if (r >= 0) {
         const RowParam &o = tab[r & (TABN - 1)];
-        mean = o.mean; ac = o.ac; mc = o.mc; melr = o.mel;
+        mean = o.mean; ac2 = o.ac * xm::LOG2E; mc2 = o.mc * xm::LOG2E; melr = o.mel;
         bs = o.bs; hi = o.hi;
         is_init = (r == top);
         if (!is_init) {
@@ -131,9 +154,21 @@ __global__ __launch_bounds__(64) void align_kernel(AlignArgs g) {
         }
       }
       int i = t_max - c * r;  // cell index of this lane at the current step
-      double out_prev = NEG, e1 = 0, e2 = 0, e3 = 0;
-      int r_old = top;                     // highest row not yet retired
+      X prev = xm::zero(), e1 = xm::one(), e2 = xm::one(), e3 = xm::one();
+      int kmax = xm::XZ;
+      int r_old = top;  // highest row not yet retired
       int filled_lo = ((t_max - c * top) / CH + 1) * CH;  // ring holds [filled_lo, filled_lo+SR)
+      // samples for step 0
+      while (t_max - c * r_old < filled_lo) {
+        filled_lo -= CH;
+        for (int q = lane; q < CH; q += 64) {
+          int idx = filled_lo + q;
+          ring[idx & RM] = (idx >= 0 && idx < N) ? sig[idx] : 0.0;
+        }
+      }
+      __syncthreads();
+      X e = density(ring[i & RM], mean, ac2, mc2);  // density of the CURRENT step, computed one step ahead
+      int su = 0, sA = sA0, sB = sB0;
 
       for (int u = 0; u < n_steps; ++u) {
         const int t = t_max - u;
@@ -149,22 +184,23 @@ __global__ __launch_bounds__(64) void align_kernel(AlignArgs g) {
           if (fin) {
             r = nr;
             i += 64 * c;
-            out_prev = NEG;
+            prev = xm::zero();
             if (r >= 0) {
               const RowParam &o = tab[r & (TABN - 1)];
               const RowParam &p = tab[(r + 1) & (TABN - 1)];
-              mean = o.mean; ac = o.ac; mc = o.mc; melr = o.mel;
+              mean = o.mean; ac2 = o.ac * xm::LOG2E; mc2 = o.mc * xm::LOG2E; melr = o.mel;
               bs = o.bs; hi = o.hi; pbs = p.bs; pbe = p.be;
               is_init = false;
+              e = density(ring[i & RM], mean, ac2, mc2);
             } else {
               hi = -0x40000000; bs = 0x40000000;
             }
           }
           while (r_old >= 0 && __shfl(r, r_old & 63, 64) != r_old) r_old--;
         }
-        // ---- signal ring: lowest sample index any live lane can touch is that of row r_old
+        // ---- signal ring, one step ahead: the next step's lowest sample index is that of row r_old
         if (r_old >= 0) {
-          int need_min = t - c * r_old;
+          int need_min = t - 1 - c * r_old;
           while (need_min < filled_lo) {
             filled_lo -= CH;
             __syncthreads();
@@ -175,44 +211,46 @@ __global__ __launch_bounds__(64) void align_kernel(AlignArgs g) {
             __syncthreads();
           }
         }
-        // ---- the cell
+        // ---- the cell (r, i): out = P * pred[i + mel] + e(s[i]) * out[i + 1]
         const bool active = (r >= 0) && (i <= hi) && (i >= bs);
-        double x = ring[i & RM];
-        double d = x - mean;
-        double e = ac - d * d * mc;
-        double P;
-        if (MEL == 0) P = 0.0;
-        else if (MEL == 1) P = e;
-        else if (MEL == 2) P = e + e1;
-        else if (MEL == 3) P = e + e1 + e2;
-        else P = e + e1 + e2 + e3;
-        if (melr == 0) P = 0.0;
+        X P = emission_product<MEL>(e, e1, e2, e3, melr);
         const int j = i + melr;
-        double pv = hist[((u - c - melr) & HM) * 64 + ((lane + 1) & 63)];
-        pv = (j >= pbs && j <= pbe) ? pv : NEG;
-        double o = lse2(P + pv, e + out_prev);
-        o = (active && (j <= N)) ? o : NEG;
-        if (is_init) o = active ? 0.0 : NEG;
-        out_prev = o;
-        e3 = e2; e2 = e1; e1 = e;
-        hist[(u & HM) * 64 + lane] = o;
-        spill[(size_t)(t - t_min) * 64 + lane] = o;
-        WAVE_SYNC();
+        const int hs = (melr == 0 ? sB : sA) * 64 + ((lane + 1) & 63);
+        X pv{hist_m[hs], hist_e[hs]};
+        pv = xm::sel(j >= pbs && j <= pbe, pv, xm::zero());
+        X o = xm::add_norm(xm::mul(P, pv), xm::mul(e, prev));
+        o = xm::sel(active && (j <= N), o, xm::zero());
+        if (is_init) o = xm::sel(active, xm::one(), xm::zero());
+        prev = o;
+        if (r == 0 && o.m != 0.0) kmax = max(kmax, o.e);
+        hist_m[su * 64 + lane] = o.m;
+        hist_e[su * 64 + lane] = o.e;
+        spill_m[(size_t)(t - t_min) * 64 + lane] = o.m;
+        spill_e[(size_t)(t - t_min) * 64 + lane] = o.e;
+        // ---- next step's density (independent of the recurrence above: overlaps with it)
         i -= 1;
+        e3 = e2; e2 = e1; e1 = e;
+        e = density(ring[i & RM], mean, ac2, mc2);
+        su = (su + 1 == H) ? 0 : su + 1;
+        sA = (sA + 1 == H) ? 0 : sA + 1;
+        sB = (sB + 1 == H) ? 0 : sB + 1;
+        WAVE_SYNC();
       }
+      K = __shfl(kmax, 0, 64);
+      if (K == xm::XZ) K = 0;
     }
     __syncthreads();
 
     // ================= forward sweep: prefix rows, posterior, path DP, update bits =================
-    double fbest = NEG;
+    X fbest = xm::zero();
     int fidx = -1;
     {
       int r = lane;
       int loaded_hi = 0;
       load_tab_block(tab, rows, 0, T, lane);
       __syncthreads();
-      double mean = 0, ac = 0, mc = 0;
-      int bs = 0, be = -1, lo = 0, pbs = 0, pbe = -1, melr = 0;
+      double mean = 0, ac2 = 0, mc2 = 0;
+      int bs = 0, be = -0x40000000, lo = 0x40000000, pbs = 0, pbe = -1, melr = 0;
       bool is_init = false;
       if (r < T) {
         const RowParam &o = tab[r & (TABN - 1)];
@@ -220,25 +258,41 @@ __global__ __launch_bounds__(64) void align_kernel(AlignArgs g) {
         is_init = (r == 0);
         if (!is_init) {
           const RowParam &p = tab[(r - 1) & (TABN - 1)];
-          mean = p.mean; ac = p.ac; mc = p.mc; melr = p.mel; pbs = p.bs; pbe = p.be;
+          mean = p.mean; ac2 = p.ac * xm::LOG2E; mc2 = p.mc * xm::LOG2E; melr = p.mel;
+          pbs = p.bs; pbe = p.be;
         }
-      } else {
-        lo = 0x40000000; be = -0x40000000;
       }
       int i = t_min - c * r;
-      double out_prev = NEG, e1 = 0, e2 = 0, e3 = 0, best = NEG;
+      X prev = xm::zero(), e1 = xm::one(), e2 = xm::one(), e3 = xm::one(), best = xm::zero();
       uint32_t bits = 0;
       int r_old = 0;  // lowest row not yet retired
       int filled_hi = ((t_min - MEL - 1) > 0 ? (t_min - MEL - 1) / CH : 0) * CH;
+      while (t_min - 1 >= filled_hi) {  // samples for step 0
+        for (int w = lane; w < CH; w += 64) {
+          int idx = filled_hi + w;
+          ring[idx & RM] = (idx >= 0 && idx < N) ? sig[idx] : 0.0;
+        }
+        filled_hi += CH;
+      }
+      __syncthreads();
+      X e = density(ring[(i - 1) & RM], mean, ac2, mc2);
+      int su = 0, sA = sA0, sB = sB0;
 
-      double cur[PF], nxt[PF];
+      // spill prefetch: the buffers are padded by 2*PF steps, so the loads are unconditional
+      double cur_m[PF], nxt_m[PF];
+      int cur_e[PF], nxt_e[PF];
 #pragma unroll
-      for (int q = 0; q < PF; q++) cur[q] = (q < n_steps) ? spill[(size_t)q * 64 + lane] : 0.0;
+      for (int q = 0; q < PF; q++) {
+        cur_m[q] = spill_m[(size_t)q * 64 + lane];
+        cur_e[q] = spill_e[(size_t)q * 64 + lane];
+      }
 
       for (int ub = 0; ub < n_steps; ub += PF) {
 #pragma unroll
-        for (int q = 0; q < PF; q++)
-          nxt[q] = (ub + PF + q < n_steps) ? spill[(size_t)(ub + PF + q) * 64 + lane] : 0.0;
+        for (int q = 0; q < PF; q++) {
+          nxt_m[q] = spill_m[(size_t)(ub + PF + q) * 64 + lane];
+          nxt_e[q] = spill_e[(size_t)(ub + PF + q) * 64 + lane];
+        }
 #pragma unroll
         for (int q = 0; q < PF; q++) {
           const int u = ub + q;
@@ -255,22 +309,24 @@ __global__ __launch_bounds__(64) void align_kernel(AlignArgs g) {
               if (fin) {
                 r = nr;
                 i -= 64 * c;
-                out_prev = NEG;
-                best = NEG;
+                prev = xm::zero();
+                best = xm::zero();
                 if (r < T) {
                   const RowParam &o = tab[r & (TABN - 1)];
                   const RowParam &p = tab[(r - 1) & (TABN - 1)];
                   bs = o.bs; be = o.be; lo = o.lo;
-                  mean = p.mean; ac = p.ac; mc = p.mc; melr = p.mel; pbs = p.bs; pbe = p.be;
+                  mean = p.mean; ac2 = p.ac * xm::LOG2E; mc2 = p.mc * xm::LOG2E; melr = p.mel;
+                  pbs = p.bs; pbe = p.be;
                   is_init = false;
+                  e = density(ring[(i - 1) & RM], mean, ac2, mc2);
                 } else {
                   lo = 0x40000000; be = -0x40000000;
                 }
               }
               while (r_old < T && __shfl(r, r_old & 63, 64) != r_old) r_old++;
             }
-            if (r_old < T) {
-              int need_max = t - c * r_old - 1;
+            if (r_old < T) {  // one step ahead
+              int need_max = t + 1 - c * r_old - 1;
               while (need_max >= filled_hi) {
                 __syncthreads();
                 for (int w = lane; w < CH; w += 64) {
@@ -281,53 +337,57 @@ __global__ __launch_bounds__(64) void align_kernel(AlignArgs g) {
                 __syncthreads();
               }
             }
+            // ---- the cell (r, i): out = P * pred[i - mel] + e(s[i-1]) * out[i - 1]
             const bool active = (r < T) && (i >= lo) && (i <= be);
             const bool in_band = active && (i >= bs);
-            double x = ring[(i - 1) & RM];
-            double d = x - mean;
-            double e = ac - d * d * mc;
-            double P;
-            if (MEL == 0) P = 0.0;
-            else if (MEL == 1) P = e;
-            else if (MEL == 2) P = e + e1;
-            else if (MEL == 3) P = e + e1 + e2;
-            else P = e + e1 + e2 + e3;
-            if (melr == 0) P = 0.0;
+            X P = emission_product<MEL>(e, e1, e2, e3, melr);
             const int j = i - melr;
             const bool ok = (j >= pbs) && (j <= pbe);
-            const int hs = ((u - c - melr) & HM) * 64 + ((lane - 1) & 63);
-            double pv = hist[hs];
-            double dv = dhist[hs];
-            pv = ok ? pv : NEG;
-            dv = ok ? dv : NEG;
-            double o = lse2(P + pv, e + out_prev);
-            o = (active && (i >= melr)) ? o : NEG;
-            if (is_init) o = in_band ? 0.0 : NEG;
-            out_prev = o;
-            e3 = e2; e2 = e1; e1 = e;
-            // posterior + max-product path (node.cpp:52-91): strict '>' keeps the first maximum
-            const bool upd = active && (dv > best);
-            best = upd ? dv : best;
+            const int hs = (melr == 0 ? sB : sA) * 64 + ((lane - 1) & 63);
+            X pv{hist_m[hs], hist_e[hs]};
+            X dv{dhist_m[hs], dhist_e[hs]};
+            pv = xm::sel(ok, pv, xm::zero());
+            dv = xm::sel(ok, dv, xm::zero());
+            X o = xm::add_norm(xm::mul(P, pv), xm::mul(e, prev));
+            o = xm::sel(active && (i >= melr), o, xm::zero());
+            if (is_init) o = xm::sel(in_band, xm::one(), xm::zero());
+            prev = o;
+            // posterior * running max of the previous row (node.cpp:52-91): strict '>' keeps
+            // the first maximum
+            const bool upd = active && xm::gt_tol(dv, best);
+            best = xm::sel(upd, dv, best);
             bits |= upd ? (1u << (u & 31)) : 0u;
-            double post = o + cur[q];
-            double dpv = is_init ? post : best + post;
-            dpv = in_band ? dpv : NEG;
-            if (r == top && in_band && dpv > fbest) {
+            X post{o.m * cur_m[q], o.e + cur_e[q] - K};
+            X dpv = is_init ? post : xm::mul(best, post);
+            dpv = xm::norm(dpv);
+            dpv = xm::sel(in_band, dpv, xm::zero());
+            if (r == top && xm::gt_tol(dpv, fbest)) {
               fbest = dpv;
               fidx = i;
             }
-            hist[(u & HM) * 64 + lane] = o;
-            dhist[(u & HM) * 64 + lane] = dpv;
+            hist_m[su * 64 + lane] = o.m;
+            hist_e[su * 64 + lane] = o.e;
+            dhist_m[su * 64 + lane] = dpv.m;
+            dhist_e[su * 64 + lane] = dpv.e;
             if ((u & 31) == 31 || u == n_steps - 1) {
               bp[(size_t)(u >> 5) * 64 + lane] = bits;
               bits = 0;
             }
-            WAVE_SYNC();
+            // ---- next step's density (overlaps with the chain above)
             i += 1;
+            e3 = e2; e2 = e1; e1 = e;
+            e = density(ring[(i - 1) & RM], mean, ac2, mc2);
+            su = (su + 1 == H) ? 0 : su + 1;
+            sA = (sA + 1 == H) ? 0 : sA + 1;
+            sB = (sB + 1 == H) ? 0 : sB + 1;
+            WAVE_SYNC();
           }
         }
 #pragma unroll
-        for (int q = 0; q < PF; q++) cur[q] = nxt[q];
+        for (int q = 0; q < PF; q++) {
+          cur_m[q] = nxt_m[q];
+          cur_e[q] = nxt_e[q];
+        }
       }
     }
     __syncthreads();
@@ -382,29 +442,30 @@ int launch_align(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadMe
     return NVK_ERR_UNSUPPORTED;
   }
   int c = tot.max_c < 1 ? 1 : tot.max_c;
-  int H = 4;
-  while (H < c + mel + 2) H <<= 1;
+  int H = c + mel + 1;  // the slot read is c+mel steps old; one more so it is not yet overwritten
   int SR = 256;
   while (SR < 64 * c + CH) SR <<= 1;
-  size_t lds = (size_t)SR * 8 + (size_t)TABN * sizeof(RowParam) + 2 * (size_t)H * 64 * 8 + 16;
+  size_t lds = (size_t)SR * 8 + (size_t)TABN * sizeof(RowParam) + 2 * (size_t)H * 64 * 12 + 16;
   if (lds > 160 * 1024) {
     nvk_set_error("band too wide for one wave per read: skew %d needs %zu bytes of LDS", c, lds);
     return NVK_ERR_UNSUPPORTED;
   }
   int max_steps = tot.max_steps < 1 ? 1 : tot.max_steps;
-  // waves resident per CU are bounded by LDS; keep at most 8 per CU (2 per SIMD)
+  // waves resident per CU are bounded by LDS; more than 4 per SIMD buys nothing here
   int per_cu = (int)((160 * 1024) / lds);
-  if (per_cu > 8) per_cu = 8;
+  if (per_cu > 16) per_cu = 16;
   if (per_cu < 1) per_cu = 1;
   int64_t slots = ctx->slots_override > 0 ? ctx->slots_override : (int64_t)ctx->num_cus * per_cu;
   if (slots > a.n_reads) slots = a.n_reads;
-  // bound the workspace: at most ~48 GiB of spill
-  const int64_t spill_stride = (int64_t)max_steps * 64;
-  const int64_t bp_stride = (int64_t)((max_steps + 31) / 32) * 64;
-  const int64_t cap = (int64_t)48 << 30;
-  while (slots > 1 && slots * spill_stride * 8 > cap) slots /= 2;
+  // per-slot workspace, padded by 2*PF steps so that prefetches past the end stay in bounds
+  const int64_t spill_stride = ((int64_t)max_steps + 2 * PF) * 64;
+  const int64_t bp_stride = (int64_t)((max_steps + 31) / 32 + 1) * 64;
+  const int64_t cap = (int64_t)64 << 30;
+  while (slots > 1 && slots * spill_stride * 12 > cap) slots /= 2;
 
   int rc = nvk_ws_reserve(ctx, WS_SPILL, (size_t)slots * spill_stride * 8);
+  if (rc) return rc;
+  rc = nvk_ws_reserve(ctx, WS_STAGE, (size_t)slots * spill_stride * 4);
   if (rc) return rc;
   rc = nvk_ws_reserve(ctx, WS_BP, (size_t)slots * bp_stride * 4);
   if (rc) return rc;
@@ -417,7 +478,8 @@ int launch_align(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadMe
   g.metas = metas;
   g.rows = rows;
   g.signal = a.signal;
-  g.spill = (double *)ctx->ws[WS_SPILL];
+  g.spill_m = (double *)ctx->ws[WS_SPILL];
+  g.spill_e = (int32_t *)ctx->ws[WS_STAGE];
   g.bp = (uint32_t *)ctx->ws[WS_BP];
   g.spill_stride = spill_stride;
   g.bp_stride = bp_stride;
@@ -428,7 +490,8 @@ int launch_align(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadMe
   g.transitions = transitions;
   g.out_events = out_events;
   g.out_status = out_status;
-  ctx->last_spill_bytes = 0;
+  // bytes the sweeps stream through HBM: 12 B written + 12 B read per (step, lane) + path bits
+  ctx->last_spill_bytes = (int64_t)tot.steps * 64 * 24 + (int64_t)tot.steps * 8 * 2;
 
   void (*kern)(AlignArgs) = nullptr;
   switch (mel) {

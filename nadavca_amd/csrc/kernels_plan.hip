@@ -7,6 +7,8 @@
 //   k-mer id / densities  nadavca/dtw/kmer_model.cpp:22-94, sequence.cpp:6-29
 // The expected-level gather (KmerModel::GetExpectedSignal, kmer_model.cpp:32-42) is the
 // last kernel in this file.
+#include <math.h>
+
 #include "nvk_internal.h"
 
 namespace {
@@ -57,7 +59,7 @@ __device__ __forceinline__ long long wave_sum(long long v) {
 
 // bandtmp: per read 2*(R+1) u64 scratch words at bandtmp[2*(ref_off+j) ...]
 __global__ __launch_bounds__(64) void plan_kernel(DeviceModel dm, BatchArgs a, int mode,
-                                                  ReadMeta *metas, RowParam *rows,
+                                                  double log_p_in, ReadMeta *metas, RowParam *rows,
                                                   unsigned long long *bandtmp,
                                                   PlanTotals *totals) {
   const int rd = blockIdx.x;
@@ -100,8 +102,8 @@ __global__ __launch_bounds__(64) void plan_kernel(DeviceModel dm, BatchArgs a, i
   int bad = (R < 1 || N < 1 || N64 > 0x3fffffff || R64 > 0x1fffffff) ? 1 : 0;
   // anchors must name an existing band row (reference writes result[reference_index])
   for (int j = lane; j < A && !bad; j += 64) {
-    int ri = anc[2 * j + 1];
-    if (ri < 0 || ri > R) bad = 1;
+    int si = anc[2 * j], ri = anc[2 * j + 1];
+    if (ri < 0 || ri > R || si < -(1 << 30) || si > (1 << 30)) bad = 1;
   }
   bad = __any(bad);
   if (bad) {
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(64) void plan_kernel(DeviceModel dm, BatchArgs a, i
     int s = anc[2 * j], ri = anc[2 * j + 1];
     long long lo = (long long)s - bw;
     long long hi = (long long)s + bw;
-    unsigned int vbs = (unsigned int)(lo > 0 ? (lo > N ? N : lo) : 0);  // max(0, s - bw)
+    unsigned int vbs = (unsigned int)(lo > 0 ? lo : 0);  // max(0, s - bw)
     // min(N, s + bw); a negative value cannot be packed: clamp to -1 -> flagged as bad band
     unsigned int vbe = (unsigned int)((hi < N ? (hi < -1 ? -1 : hi) : N) + 1);
     unsigned long long tag = ((unsigned long long)(j + 1)) << 32;
@@ -163,7 +165,6 @@ __global__ __launch_bounds__(64) void plan_kernel(DeviceModel dm, BatchArgs a, i
 
   // --- row table -----------------------------------------------------------------------------
   RowParam *rp = rows + m.row_off;
-  const double log_p_in = log(0.01);
   int badband = 0;
   long long cells = 0;
   for (int r = lane; r < T; r += 64) {
@@ -178,11 +179,8 @@ __global__ __launch_bounds__(64) void plan_kernel(DeviceModel dm, BatchArgs a, i
     p.mean = 0.0;
     p.ac = 0.0;
     p.mc = 0.0;
-    p.mean2 = 0.0;
-    p.ac2 = 0.0;
-    p.mc2 = 0.0;
     p.mel = 0;
-    p.kind = 0;
+    p.pad = 0;
     if (r + 1 < T) {
       if (mode == PLAN_ALIGN_TRANS && (r & 1)) {
         // transition step between base r/2 and r/2+1: constant log(0.01), -inf on equal means
@@ -279,8 +277,10 @@ int launch_plan(nvk_ctx *ctx, const DeviceModel &dm, const BatchArgs &a, int mod
   if (a.n_reads == 0) return NVK_OK;
   {
     TimerScope ts(ctx, NVK_K_PLAN);
+    // the transition constant comes from the host libm, like the model's ac/mc (kmer_model.cpp:77)
+    const double log_p_in = log(0.01);
     hipLaunchKernelGGL(plan_kernel, dim3((unsigned)a.n_reads), dim3(64), 0, ctx->stream, dm, a, mode,
-                       metas, rows, bandtmp, totals);
+                       log_p_in, metas, rows, bandtmp, totals);
   }
   NVK_HIP(hipGetLastError());
   return NVK_OK;

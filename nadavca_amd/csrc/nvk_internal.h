@@ -13,13 +13,12 @@
 // with mc = 0 and ac = the constant.
 struct __attribute__((aligned(16))) RowParam {
   double mean, ac, mc;     // step r -> r+1 : e(x) = ac - (x-mean)^2 * mc
-  double mean2, ac2, mc2;  // second component for mixture (wobble) steps
   int32_t bs, be;          // band of row r, inclusive sample-boundary indices
   int32_t lo, hi;          // lane occupancy of row r: band + warm-up/pre-roll on both sides
   int32_t mel;             // min event length of step r -> r+1
-  int32_t kind;            // 0 gauss/const, 1 mixture
+  int32_t pad;
 };
-static_assert(sizeof(RowParam) == 80, "RowParam layout");
+static_assert(sizeof(RowParam) == 48, "RowParam layout");
 
 struct ReadMeta {
   int64_t sig_off;   // first sample of the read's signal slice
