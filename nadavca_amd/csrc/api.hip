@@ -496,3 +496,103 @@ extern "C" int nvk_refine_alignment_batch(nvk_model *model, int64_t n_reads, con
   NVK_HIP(hipStreamSynchronize(ctx->stream));
   return NVK_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// estimate_log_likelihoods
+// ---------------------------------------------------------------------------------------------
+extern "C" int nvk_estimate_log_likelihoods_batch_dev(
+    nvk_model *model, int64_t n_reads, int64_t total_signal, int64_t total_ref,
+    int64_t total_anchors, const double *signal, const int64_t *sig_off, const int32_t *reference,
+    const int64_t *ref_off, const int32_t *ctx_before, const int64_t *cb_off,
+    const int32_t *ctx_after, const int64_t *ca_off, const int32_t *anchors,
+    const int64_t *anc_off, int bandwidth, int min_event_length, int model_wobbling,
+    double *out_ll, int32_t *out_status) {
+  int rc = check_common(model, n_reads, bandwidth, min_event_length);
+  if (rc) return rc;
+  if (min_event_length > 4) {
+    nvk_set_error("min_event_length %d outside the compiled range 0..4", min_event_length);
+    return NVK_ERR_UNSUPPORTED;
+  }
+  nvk_ctx *ctx = model->ctx;
+  NVK_HIP(hipSetDevice(ctx->device));
+  if (n_reads == 0) return NVK_OK;
+  BatchArgs a;
+  memset(&a, 0, sizeof a);
+  a.n_reads = n_reads;
+  a.total_signal = total_signal;
+  a.total_ref = total_ref;
+  a.total_anchors = total_anchors;
+  a.signal = signal;
+  a.sig_off = sig_off;
+  a.reference = reference;
+  a.ref_off = ref_off;
+  a.ctx_before = ctx_before;
+  a.cb_off = cb_off;
+  a.ctx_after = ctx_after;
+  a.ca_off = ca_off;
+  a.anchors = anchors;
+  a.anc_off = anc_off;
+  a.bandwidth = bandwidth;
+  a.mel = min_event_length;
+
+  const int64_t n = n_reads, nrow = total_ref + n;
+  if ((rc = nvk_ws_reserve(ctx, WS_META, (size_t)(n + 1) * sizeof(ReadMeta) + 64))) return rc;
+  if ((rc = nvk_ws_reserve(ctx, WS_ROWS, (size_t)(total_ref + 1) * sizeof(FusedParam)))) return rc;
+  if ((rc = nvk_ws_reserve(ctx, WS_ROWS2, (size_t)(total_ref + 1) * sizeof(FusedParam)))) return rc;
+  if ((rc = nvk_ws_reserve(ctx, WS_BP, (size_t)(3 * nrow + 16) * sizeof(int32_t)))) return rc;
+  if ((rc = nvk_ws_reserve(ctx, WS_BANDTMP, (size_t)(2 * nrow + 2) * 8))) return rc;
+  if ((rc = nvk_ws_reserve(ctx, WS_MISC, 256))) return rc;
+  EllPlan pl;
+  pl.metas = (ReadMeta *)ctx->ws[WS_META];
+  pl.fwd = (FusedParam *)ctx->ws[WS_ROWS];
+  pl.rev = (FusedParam *)ctx->ws[WS_ROWS2];
+  pl.bs = (int32_t *)ctx->ws[WS_BP];
+  pl.be = pl.bs + nrow;
+  pl.rowoff = pl.be + nrow;
+  PlanTotals *d_tot = (PlanTotals *)((char *)ctx->ws[WS_MISC] + 64);
+  rc = launch_plan_ell(ctx, model->dm, a, model_wobbling ? 1 : 0, pl,
+                       (unsigned long long *)ctx->ws[WS_BANDTMP], d_tot);
+  if (rc) return rc;
+  PlanTotals tot;
+  NVK_HIP(hipMemcpyAsync(&tot, d_tot, sizeof(PlanTotals), hipMemcpyDeviceToHost, ctx->stream));
+  NVK_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->last_cells = (int64_t)tot.cells;
+  ctx->last_steps = (int64_t)tot.steps;
+  rc = launch_ell(ctx, model->dm, a, model_wobbling ? 1 : 0, pl, tot, out_ll, out_status);
+  if (rc) return rc;
+  NVK_HIP(hipStreamSynchronize(ctx->stream));
+  return NVK_OK;
+}
+
+extern "C" int nvk_estimate_log_likelihoods_batch(
+    nvk_model *model, int64_t n_reads, const double *signal, const int64_t *sig_off,
+    const int32_t *reference, const int64_t *ref_off, const int32_t *ctx_before,
+    const int64_t *cb_off, const int32_t *ctx_after, const int64_t *ca_off,
+    const int32_t *anchors, const int64_t *anc_off, int bandwidth, int min_event_length,
+    int model_wobbling, double *out_ll, int32_t *out_status) {
+  int rc = check_common(model, n_reads, bandwidth, min_event_length);
+  if (rc) return rc;
+  if (n_reads == 0) return NVK_OK;
+  nvk_ctx *ctx = model->ctx;
+  NVK_HIP(hipSetDevice(ctx->device));
+  StagedBatch sb;
+  rc = stage_batch(ctx, n_reads, signal, sig_off, reference, ref_off, ctx_before, cb_off, ctx_after,
+                   ca_off, anchors, anc_off, bandwidth, min_event_length, true, sb);
+  if (rc) return rc;
+  const int alpha = model->dm.alphabet;
+  DevBuf d_ll, d_st;
+  size_t llb = (size_t)sb.a.total_ref * alpha * 8, stb = (size_t)n_reads * 4;
+  if ((rc = d_ll.alloc(llb))) return rc;
+  if ((rc = d_st.alloc(stb))) return rc;
+  NVK_HIP(hipMemsetAsync(d_ll.p, 0, llb ? llb : 16, ctx->stream));
+  rc = nvk_estimate_log_likelihoods_batch_dev(
+      model, n_reads, sb.a.total_signal, sb.a.total_ref, sb.a.total_anchors, sb.a.signal,
+      sb.a.sig_off, sb.a.reference, sb.a.ref_off, sb.a.ctx_before, sb.a.cb_off, sb.a.ctx_after,
+      sb.a.ca_off, sb.a.anchors, sb.a.anc_off, bandwidth, min_event_length, model_wobbling,
+      (double *)d_ll.p, (int32_t *)d_st.p);
+  if (rc) return rc;
+  if (llb) NVK_HIP(hipMemcpyAsync(out_ll, d_ll.p, llb, hipMemcpyDeviceToHost, ctx->stream));
+  NVK_HIP(hipMemcpyAsync(out_status, d_st.p, stb, hipMemcpyDeviceToHost, ctx->stream));
+  NVK_HIP(hipStreamSynchronize(ctx->stream));
+  return NVK_OK;
+}

@@ -1,0 +1,515 @@
+// estimate_log_likelihoods on gfx950 (reference: nadavca/dtw/dtw.cpp:37-131; semantics in
+// SURVEY.md Appendix A.5, including its two load-bearing quirks).
+//
+// Per read, one wave64 (persistent, pulls reads from a counter):
+//   A. prefix sweep    prefix[0..R]   (dtw.cpp:50-64)
+//   B. suffix sweep    suffix[R..0]   (dtw.cpp:66-81) — run as a FORWARD sweep on mirrored
+//                      coordinates i' = N - i, so one code path serves both directions
+//   C. hypotheses      for every position p and every substituted base b != ref[p]: re-run the
+//                      <= k rows the substitution influences, starting from prefix[first] and
+//                      closing against suffix[last+1] (dtw.cpp:93-129)
+//
+// Mapping (not the reference's): "fused" lanes.  The reference alternates a wobble row
+// (mixture of the k-mers j-1 and j, min event length 0) with an emitting row (k-mer j).  Both
+// are computed by ONE lane per base position j: the mixture needs the emitting Gaussian anyway,
+// so a lane evaluates two densities and advances two rows per step.  Lanes of consecutive
+// positions form a systolic wavefront (cell i of position j at step i + c*j), handing the
+// emitting row to the neighbour through a small LDS ring.  All probabilities are scaled linear
+// numbers (xmath.h); natural logs are taken once per output value.
+//
+// Sweep rows are kept row-major in a per-slot row store (12 B per cell) so that phase C reads
+// them with unit stride.  Phase C packs 8 hypotheses per wave step, 8 lanes each: up to k fused
+// positions plus one closing lane that applies the last wobble row and accumulates
+// sum_x cur[x] * suffix[last+1][x].
+//
+// Quirks kept on purpose: the mixture is (g1 + g2) * exp(-2), not / 2; the
+// closing wobble row of a hypothesis lives on band row `last`, not `last + 1`.
+#include <math.h>
+
+#include "nvk_internal.h"
+#include "xmath.h"
+
+namespace {
+
+using xm::X;
+
+constexpr int CH = 128;    // signal refill chunk (samples)
+constexpr int TABN = 128;  // descriptor window (two 64-position blocks)
+constexpr int PF = 4;      // phase C prefetch depth (steps)
+constexpr int GL = 8;      // lanes per hypothesis group (k + 1 <= GL)
+
+#define WAVE_SYNC()                                        \
+  do {                                                     \
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); \
+    __builtin_amdgcn_wave_barrier();                       \
+  } while (0)
+
+struct EllArgs {
+  DeviceModel dm;
+  BatchArgs a;
+  EllPlan pl;
+  double *store_m;  // row store mantissas: [slot][2][cells]  (prefix rows, then suffix rows)
+  int32_t *store_e;
+  int64_t store_stride;  // cells per slot (both halves)
+  int64_t half;          // cells per half
+  int n_reads;
+  int *counter;
+  int H, SR;
+  int wobbling;
+  double *out_ll;
+  int32_t *out_status;
+};
+
+__device__ __forceinline__ X density(double x, double mean, double ac2, double mc2) {
+  double d = x - mean;
+  return xm::from_log2(ac2 - d * d * mc2);  // kmer_model.cpp:48-50, in base-2 logs
+}
+
+// exp(-2): the reference divides the mixture by Probability(2) == exp(2) (kmer_model.cpp:59-61)
+__device__ __forceinline__ X expm2() { return X{0x1.152aaa3bf81ccp+0, -3}; }
+
+// per-lane description of one fused position
+struct LaneDesc {
+  double am, aac2, amc2, bm, bac2, bmc2;
+  int wbs, wbe;  // wobble-row band (== band the lane starts on)
+  int ebe;       // last cell of the emitting row
+  int pbs, pbe;  // band of the predecessor row (values outside read as zero)
+  int has_wob;
+};
+
+template <int MEL>
+struct LaneState {
+  X wq[MEL + 1];  // wobble-row values at cells i, i-1, ..., i-MEL
+  X em;           // emitting-row value at the previous cell
+  X gh[MEL > 0 ? MEL : 1];  // emitting densities of the previous MEL-1.. cells
+  __device__ __forceinline__ void reset() {
+#pragma unroll
+    for (int k = 0; k <= MEL; k++) wq[k] = xm::zero();
+    em = xm::zero();
+#pragma unroll
+    for (int k = 0; k < (MEL > 0 ? MEL : 1); k++) gh[k] = xm::one();
+  }
+};
+
+// One step of a fused lane at cell i (sample x = s[i-1]); pred = predecessor row at cell i.
+// Returns the emitting-row value at cell i (zero outside its range).  The wobble value of this
+// cell is left in st.wq[0].
+template <int MEL>
+__device__ __forceinline__ X fused_step(const LaneDesc &d, LaneState<MEL> &st, int i, double x,
+                                        X pred, bool on) {
+  X gb = density(x, d.bm, d.bac2, d.bmc2);
+  X ga = density(x, d.am, d.aac2, d.amc2);
+  X mix = xm::mul(xm::add_norm(ga, gb), expm2());
+  X wn = xm::add_norm(pred, xm::mul(mix, st.wq[0]));  // node_next_row.h with mel = 0
+  wn = xm::sel(d.has_wob != 0, wn, pred);
+  wn = xm::sel(on && i >= d.wbs && i <= d.wbe, wn, xm::zero());
+#pragma unroll
+  for (int k = MEL; k >= 1; k--) st.wq[k] = st.wq[k - 1];
+  st.wq[0] = wn;
+  X P = xm::one();
+  if (MEL >= 1) {
+    P = gb;
+#pragma unroll
+    for (int k = 0; k < MEL - 1; k++) P = xm::mul(P, st.gh[k]);
+  }
+  X en = xm::add_norm(xm::mul(P, st.wq[MEL]), xm::mul(gb, st.em));
+  en = xm::sel(on && i >= MEL && i <= d.ebe, en, xm::zero());
+  st.em = en;
+  if (MEL >= 2) {
+#pragma unroll
+    for (int k = MEL - 2; k >= 1; k--) st.gh[k] = st.gh[k - 1];
+    st.gh[0] = gb;
+  }
+  return en;
+}
+
+__device__ __forceinline__ void load_desc(LaneDesc &d, const FusedParam &f) {
+  d.am = f.a_mean; d.aac2 = f.a_ac * xm::LOG2E; d.amc2 = f.a_mc * xm::LOG2E;
+  d.bm = f.b_mean; d.bac2 = f.b_ac * xm::LOG2E; d.bmc2 = f.b_mc * xm::LOG2E;
+  d.wbs = f.wbs; d.wbe = f.wbe; d.ebe = f.ebe;
+  d.pbs = f.wbs; d.pbe = f.wbe;
+  d.has_wob = f.has_wob;
+}
+
+__device__ __forceinline__ void load_tab_block(FusedParam *tab, const FusedParam *src, int blk,
+                                               int R, int lane) {
+  int j = blk * 64 + lane;
+  if (j >= 0 && j < R) tab[j & (TABN - 1)] = src[j];
+}
+
+// k-mer id of position pos with base `p` replaced by `b` (sequence.cpp:31-38, kmer_model.cpp:22-30)
+__device__ __forceinline__ int64_t kmer_id_mod(const DeviceModel &dm, const int32_t *ref, int R,
+                                               const int32_t *cb, int nb, const int32_t *ca, int na,
+                                               int pos, int p, int b) {
+  int64_t id = 0;
+  for (int j = pos - dm.central; j < pos - dm.central + dm.k; j++) {
+    int v;
+    if (j == p) v = b;
+    else if (j < 0) v = (j + nb >= 0) ? cb[j + nb] : 0;
+    else if (j < R) v = ref[j];
+    else v = (j - R < na) ? ca[j - R] : 0;
+    id = id * dm.alphabet + v;
+  }
+  return id;
+}
+
+// one sweep over the R fused positions of `desc` (prefix order or mirrored suffix order)
+template <int MEL>
+__device__ void sweep(const FusedParam *desc, int R, int N, int c, const double *sig, bool mirror,
+                      double *ring, int RM, FusedParam *tab, double *hist_m, int *hist_e, int H,
+                      double *st_m, int32_t *st_e, int lane) {
+  // the predecessor of position 0 is the all-ones row on its band (prefix[0] / suffix[R])
+  int r_old = 0, loaded_hi = 0;
+  load_tab_block(tab, desc, 0, R, lane);
+  __syncthreads();
+  int j = lane;
+  LaneDesc d;
+  int ebs = 0, soff = 0;
+  d.wbs = 0x40000000; d.wbe = -0x40000000; d.ebe = -0x40000000; d.pbs = 0; d.pbe = -1;
+  d.has_wob = 0; d.am = d.aac2 = d.amc2 = d.bm = d.bac2 = d.bmc2 = 0.0;
+  if (j < R) {
+    const FusedParam &f = tab[j & (TABN - 1)];
+    load_desc(d, f);
+    ebs = f.ebs; soff = f.store_off;
+  }
+  const int t_min = __shfl(d.wbs, 0, 64);
+  const FusedParam &lastf = desc[R - 1];
+  const int t_max = lastf.ebe + c * (R - 1);
+  const int n_steps = t_max - t_min + 1;
+  LaneState<MEL> st;
+  st.reset();
+  int i = t_min - c * j;
+  int filled_hi = ((t_min - 1) > 0 ? (t_min - 1) / CH : 0) * CH;
+  auto fill = [&](int upto) {
+    while (upto >= filled_hi) {
+      __syncthreads();
+      for (int w = lane; w < CH; w += 64) {
+        int idx = filled_hi + w;
+        int src = mirror ? (N - 1 - idx) : idx;
+        ring[idx & RM] = (idx >= 0 && idx < N) ? sig[src] : 0.0;
+      }
+      filled_hi += CH;
+      __syncthreads();
+    }
+  };
+  fill(t_min);
+  int su = 0, sr = ((-c) % H + H) % H;
+  for (int u = 0; u < n_steps; ++u) {
+    const int t = t_min + u;
+    bool fin = (j < R) && (i > d.ebe);
+    if (__any(fin)) {
+      int nj = j + 64;
+      if (__any(fin && nj < R && (nj >> 6) > loaded_hi)) {
+        loaded_hi++;
+        load_tab_block(tab, desc, loaded_hi, R, lane);
+        __syncthreads();
+      }
+      if (fin) {
+        j = nj;
+        i -= 64 * c;
+        st.reset();
+        if (j < R) {
+          const FusedParam &f = tab[j & (TABN - 1)];
+          load_desc(d, f);
+          ebs = f.ebs; soff = f.store_off;
+        } else {
+          d.wbs = 0x40000000; d.wbe = -0x40000000; d.ebe = -0x40000000;
+        }
+      }
+      while (r_old < R && __shfl(j, r_old & 63, 64) != r_old) r_old++;
+    }
+    if (r_old < R) fill(t - c * r_old);
+    const bool on = (j < R) && (i >= d.wbs) && (i <= d.ebe);
+    const int hs = sr * 64 + ((lane - 1) & 63);
+    X pred{hist_m[hs], hist_e[hs]};
+    pred = xm::sel(i >= d.pbs && i <= d.pbe, pred, xm::zero());
+    if (j == 0) pred = xm::sel(i >= d.pbs && i <= d.pbe, xm::one(), xm::zero());
+    X en = fused_step<MEL>(d, st, i, ring[(i - 1) & RM], pred, on);
+    hist_m[su * 64 + lane] = en.m;
+    hist_e[su * 64 + lane] = en.e;
+    if (on && i >= ebs) {  // row-major store, un-mirrored cell index
+      int off = soff + (mirror ? (d.ebe - i) : (i - ebs));
+      st_m[off] = en.m;
+      st_e[off] = en.e;
+    }
+    i += 1;
+    su = (su + 1 == H) ? 0 : su + 1;
+    sr = (sr + 1 == H) ? 0 : sr + 1;
+    WAVE_SYNC();
+  }
+}
+
+template <int MEL>
+__global__ __launch_bounds__(64) void ell_kernel(EllArgs g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double *ring = reinterpret_cast<double *>(smem);
+  FusedParam *tab = reinterpret_cast<FusedParam *>(ring + g.SR);
+  double *hist_m = reinterpret_cast<double *>(tab + TABN);
+  int *hist_e = reinterpret_cast<int *>(hist_m + (size_t)g.H * 64);
+  int *s_read = hist_e + (size_t)g.H * 64;
+
+  const int lane = threadIdx.x;
+  const int RM = g.SR - 1;
+  const DeviceModel dm = g.dm;
+  const int alpha = dm.alphabet;
+  double *pre_m = g.store_m + (size_t)blockIdx.x * g.store_stride;
+  int32_t *pre_e = g.store_e + (size_t)blockIdx.x * g.store_stride;
+  double *suf_m = pre_m + g.half;
+  int32_t *suf_e = pre_e + g.half;
+  for (int q = lane; q < g.SR; q += 64) ring[q] = 0.0;
+
+  while (true) {
+    __syncthreads();
+    if (lane == 0) *s_read = atomicAdd(g.counter, 1);
+    __syncthreads();
+    const int rd = __builtin_amdgcn_readfirstlane(*s_read);
+    if (rd >= g.n_reads) break;
+    const ReadMeta m = g.pl.metas[rd];
+    const int R = __builtin_amdgcn_readfirstlane(m.R);
+    double *out = g.out_ll + (size_t)m.ref_off * alpha;
+    if (m.status != NVK_READ_OK) {
+      if (lane == 0) g.out_status[rd] = m.status;
+      continue;
+    }
+    const int N = __builtin_amdgcn_readfirstlane(m.N);
+    const int c = __builtin_amdgcn_readfirstlane(m.c);
+    const double *sig = g.a.signal + m.sig_off;
+    const int32_t *ref = g.a.reference + m.ref_off;
+    const int nb = (int)(g.a.cb_off[rd + 1] - g.a.cb_off[rd]);
+    const int na = (int)(g.a.ca_off[rd + 1] - g.a.ca_off[rd]);
+    const int32_t *cb = g.a.ctx_before + g.a.cb_off[rd];
+    const int32_t *ca = g.a.ctx_after + g.a.ca_off[rd];
+    const int32_t *bs = g.pl.bs + m.ref_off + rd;
+    const int32_t *be = g.pl.be + m.ref_off + rd;
+    const int32_t *rowoff = g.pl.rowoff + m.ref_off + rd;
+
+    // rows that are all ones: prefix[0] on band 0, suffix[R] on band R (dtw.cpp:50,66-67)
+    for (int x = bs[0] + lane; x <= be[0]; x += 64) {
+      pre_m[rowoff[0] + x - bs[0]] = 0.5;
+      pre_e[rowoff[0] + x - bs[0]] = 1;
+    }
+    for (int x = bs[R] + lane; x <= be[R]; x += 64) {
+      suf_m[rowoff[R] + x - bs[R]] = 0.5;
+      suf_e[rowoff[R] + x - bs[R]] = 1;
+    }
+    // ---- A, B: the two sweeps
+    sweep<MEL>(g.pl.fwd + m.row_off, R, N, c, sig, false, ring, RM, tab, hist_m, hist_e, g.H, pre_m,
+               pre_e, lane);
+    __syncthreads();
+    sweep<MEL>(g.pl.rev + m.row_off, R, N, c, sig, true, ring, RM, tab, hist_m, hist_e, g.H, suf_m,
+               suf_e, lane);
+    __syncthreads();
+
+    // ---- no-substitution likelihood: sum_x prefix[R][x] * suffix[R][x]  (dtw.cpp:83-85)
+    X tot = xm::zero();
+    for (int x = bs[R] + lane; x <= be[R]; x += 64) {
+      int o = rowoff[R] + x - bs[R];
+      X v = xm::mul(X{pre_m[o], pre_e[o]}, X{suf_m[o], suf_e[o]});
+      tot = xm::add_norm(tot, v);
+    }
+    for (int dlt = 32; dlt >= 1; dlt >>= 1) {
+      X o{__shfl_xor(tot.m, dlt, 64), __shfl_xor(tot.e, dlt, 64)};
+      tot = xm::add_norm(tot, o);
+    }
+    const double no_snp = xm::to_log(tot);
+    for (int p = lane; p < R; p += 64) out[(size_t)p * alpha + ref[p]] = no_snp;
+
+    // ---- C: substitution hypotheses, 8 per wave step
+    const int back = dm.k - dm.central - 1, fwd = dm.central;
+    const int n_items = R * (alpha - 1);
+    const int grp = lane / GL, gl = lane % GL;
+    for (int b0 = 0; b0 < n_items; b0 += 64 / GL) {
+      const int item = b0 + grp;
+      const bool valid = item < n_items;
+      int p = 0, b = 0, first = 0, last = 0, npos = 0;
+      if (valid) {
+        p = item / (alpha - 1);
+        int bi = item % (alpha - 1);
+        b = bi + (bi >= ref[p] ? 1 : 0);
+        first = max(0, p - back);
+        last = min(R - 1, p + fwd);
+        npos = last - first + 1;
+      }
+      // role of this lane inside its group
+      const bool is_pos = valid && gl < npos;
+      const bool is_fin = valid && gl == npos;
+      LaneDesc d;
+      d.wbs = 0x40000000; d.wbe = -0x40000000; d.ebe = -0x40000000; d.pbs = 0; d.pbe = -1;
+      d.has_wob = 0; d.am = d.aac2 = d.amc2 = d.bm = d.bac2 = d.bmc2 = 0.0;
+      // input stream of the lane: prefix[first] for the group's first lane, suffix[last+1] for
+      // the closing lane; index of cell i in the row store = sbase + i, valid for i in [slo, shi]
+      const double *sm = pre_m;
+      const int32_t *se = pre_e;
+      int sbase = 0, slo = 0x40000000, shi = -0x40000000;
+      if (is_pos) {
+        const int j = first + gl;
+        int64_t idb = kmer_id_mod(dm, ref, R, cb, nb, ca, na, j, p, b);
+        d.bm = dm.mean[idb]; d.bac2 = dm.ac[idb] * xm::LOG2E; d.bmc2 = dm.mc[idb] * xm::LOG2E;
+        d.has_wob = (j > 0 && g.wobbling) ? 1 : 0;
+        if (d.has_wob) {
+          int64_t ida = kmer_id_mod(dm, ref, R, cb, nb, ca, na, j - 1, p, b);
+          d.am = dm.mean[ida]; d.aac2 = dm.ac[ida] * xm::LOG2E; d.amc2 = dm.mc[ida] * xm::LOG2E;
+        }
+        d.wbs = bs[j]; d.wbe = be[j]; d.ebe = be[j + 1];
+        d.pbs = d.wbs; d.pbe = d.wbe;
+        if (gl == 0) {
+          sbase = rowoff[first] - bs[first];
+          slo = bs[first]; shi = be[first];
+        }
+      } else if (is_fin) {
+        // closing lane: optional wobble row on band `last` (quirk), predecessor = emitting row of
+        // position `last` on band last+1; then the running total against suffix[last+1]
+        d.has_wob = (last + 1 < R && g.wobbling) ? 1 : 0;
+        if (d.has_wob) {
+          int64_t ida = kmer_id_mod(dm, ref, R, cb, nb, ca, na, last, p, b);
+          int64_t idb = kmer_id_mod(dm, ref, R, cb, nb, ca, na, last + 1, p, b);
+          d.am = dm.mean[ida]; d.aac2 = dm.ac[ida] * xm::LOG2E; d.amc2 = dm.mc[ida] * xm::LOG2E;
+          d.bm = dm.mean[idb]; d.bac2 = dm.ac[idb] * xm::LOG2E; d.bmc2 = dm.mc[idb] * xm::LOG2E;
+          d.wbs = bs[last]; d.wbe = be[last];
+        } else {
+          d.wbs = bs[last + 1]; d.wbe = be[last + 1];
+        }
+        d.pbs = bs[last + 1]; d.pbe = be[last + 1];
+        d.ebe = d.wbe;
+        sm = suf_m; se = suf_e;
+        sbase = rowoff[last + 1] - bs[last + 1];
+        slo = bs[last + 1]; shi = be[last + 1];
+      }
+      // group-local wavefront: lane gl is at cell i = base + tau - gl
+      const int base = valid ? bs[first] : 0;
+      int steps = 0;
+      if (is_fin) steps = d.wbe - base + gl + 1;
+      for (int dlt = 32; dlt >= 1; dlt >>= 1) steps = max(steps, __shfl_xor(steps, dlt, 64));
+      const int i0 = base - gl;
+      const int smax = (int)g.half - 1;
+      LaneState<MEL> st;
+      st.reset();
+      X acc = xm::zero();
+      // prefetch rings: sample s[i-1] and the lane's input stream at cell i
+      double cx[PF], nx[PF], cm[PF], nm[PF];
+      int ce[PF], ne[PF];
+      auto sidx = [&](int i) { return min(max(sbase + i, 0), smax); };
+      auto xidx = [&](int i) { return min(max(i - 1, 0), N - 1); };
+#pragma unroll
+      for (int q = 0; q < PF; q++) {
+        cx[q] = sig[xidx(i0 + q)];
+        cm[q] = sm[sidx(i0 + q)];
+        ce[q] = se[sidx(i0 + q)];
+      }
+      __syncthreads();
+      for (int ub = 0; ub < steps; ub += PF) {
+#pragma unroll
+        for (int q = 0; q < PF; q++) {
+          nx[q] = sig[xidx(i0 + ub + PF + q)];
+          nm[q] = sm[sidx(i0 + ub + PF + q)];
+          ne[q] = se[sidx(i0 + ub + PF + q)];
+        }
+#pragma unroll
+        for (int q = 0; q < PF; q++) {
+          const int u = ub + q;
+          if (u < steps) {
+            const int i = i0 + u;
+            const bool on = (is_pos || is_fin) && i >= d.wbs && i <= d.ebe;
+            X sv{cm[q], ce[q]};
+            sv = xm::sel(i >= slo && i <= shi, sv, xm::zero());
+            // predecessor: neighbour lane's emitting row from the previous step (skew 1)
+            const int hs = ((u + 1) & 1) * 64 + ((lane - 1) & 63);
+            X pred{hist_m[hs], hist_e[hs]};
+            pred = xm::sel(i >= d.pbs && i <= d.pbe, pred, xm::zero());
+            if (gl == 0) pred = sv;  // prefix[first] (already masked to its band)
+            X en = fused_step<MEL>(d, st, i, cx[q], pred, on);
+            hist_m[(u & 1) * 64 + lane] = en.m;
+            hist_e[(u & 1) * 64 + lane] = en.e;
+            if (is_fin) acc = xm::add_norm(acc, xm::mul(st.wq[0], sv));  // node.cpp:31-37
+            WAVE_SYNC();
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < PF; q++) {
+          cx[q] = nx[q];
+          cm[q] = nm[q];
+          ce[q] = ne[q];
+        }
+      }
+      if (is_fin) out[(size_t)p * alpha + b] = xm::to_log(acc);
+    }
+    if (lane == 0) g.out_status[rd] = NVK_READ_OK;
+  }
+}
+
+}  // namespace
+
+int launch_ell(nvk_ctx *ctx, const DeviceModel &dm, const BatchArgs &a, int wobbling,
+               const EllPlan &pl, const PlanTotals &tot, double *out_ll, int32_t *out_status) {
+  if (a.n_reads == 0) return NVK_OK;
+  const int mel = a.mel;
+  if (mel < 0 || mel > 4) {
+    nvk_set_error("min_event_length %d outside the compiled range 0..4", mel);
+    return NVK_ERR_UNSUPPORTED;
+  }
+  if (dm.k + 1 > GL) {
+    nvk_set_error("k-mer size %d needs %d lanes per hypothesis, compiled limit is %d", dm.k, dm.k + 1, GL);
+    return NVK_ERR_UNSUPPORTED;
+  }
+  int c = tot.max_c < 1 ? 1 : tot.max_c;
+  int H = c + 1;
+  if (H < 2) H = 2;
+  int SR = 256;
+  while (SR < 64 * c + CH) SR <<= 1;
+  size_t lds = (size_t)SR * 8 + (size_t)TABN * sizeof(FusedParam) + (size_t)H * 64 * 12 + 16;
+  if (lds > 160 * 1024) {
+    nvk_set_error("band too wide for one wave per read: skew %d needs %zu bytes of LDS", c, lds);
+    return NVK_ERR_UNSUPPORTED;
+  }
+  int per_cu = (int)((160 * 1024) / lds);
+  if (per_cu > 12) per_cu = 12;
+  if (per_cu < 1) per_cu = 1;
+  int64_t slots = ctx->slots_override > 0 ? ctx->slots_override : (int64_t)ctx->num_cus * per_cu;
+  if (slots > a.n_reads) slots = a.n_reads;
+  const int64_t half = (int64_t)(tot.max_W > 0 ? tot.max_W : 1) + 64;
+  const int64_t stride = 2 * half;
+  const int64_t cap = (int64_t)64 << 30;
+  while (slots > 1 && slots * stride * 12 > cap) slots /= 2;
+  int rc = nvk_ws_reserve(ctx, WS_SPILL, (size_t)slots * stride * 8);
+  if (rc) return rc;
+  rc = nvk_ws_reserve(ctx, WS_STAGE, (size_t)slots * stride * 4);
+  if (rc) return rc;
+  rc = nvk_ws_reserve(ctx, WS_MISC, 256);
+  if (rc) return rc;
+  int *counter = (int *)ctx->ws[WS_MISC];
+  NVK_HIP(hipMemsetAsync(counter, 0, sizeof(int), ctx->stream));
+
+  EllArgs g;
+  g.dm = dm;
+  g.a = a;
+  g.pl = pl;
+  g.store_m = (double *)ctx->ws[WS_SPILL];
+  g.store_e = (int32_t *)ctx->ws[WS_STAGE];
+  g.store_stride = stride;
+  g.half = half;
+  g.n_reads = (int)a.n_reads;
+  g.counter = counter;
+  g.H = H;
+  g.SR = SR;
+  g.wobbling = wobbling;
+  g.out_ll = out_ll;
+  g.out_status = out_status;
+  ctx->last_spill_bytes = (int64_t)tot.cells * 24 * 2;
+
+  void (*kern)(EllArgs) = nullptr;
+  switch (mel) {
+    case 0: kern = ell_kernel<0>; break;
+    case 1: kern = ell_kernel<1>; break;
+    case 2: kern = ell_kernel<2>; break;
+    case 3: kern = ell_kernel<3>; break;
+    default: kern = ell_kernel<4>; break;
+  }
+  if (lds > 64 * 1024)
+    NVK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  {
+    TimerScope ts(ctx, NVK_K_ELL_HYP);
+    hipLaunchKernelGGL(kern, dim3((unsigned)slots), dim3(64), lds, ctx->stream, g);
+  }
+  NVK_HIP(hipGetLastError());
+  return NVK_OK;
+}

@@ -57,6 +57,60 @@ __device__ __forceinline__ long long wave_sum(long long v) {
   return v;
 }
 
+// bands of the R+1 boundary rows (dtw.cpp:7-35): "later anchor overwrites", then
+// prefix-max / suffix-min.  Results are left in the low words of tbs[] / tbe[].
+__device__ void plan_bands(const int32_t *anc, int A, int R, int N, int bw,
+                           unsigned long long *tbs, unsigned long long *tbe, int lane) {
+  // scratch word = (anchor ordinal + 1) << 32 | payload ; atomicMax keeps the last anchor
+  for (int j = lane; j <= R; j += 64) {
+    tbs[j] = 0ull;
+    tbe[j] = 0ull;
+  }
+  __syncthreads();
+  for (int j = lane; j < A; j += 64) {
+    int s = anc[2 * j], ri = anc[2 * j + 1];
+    long long lo = (long long)s - bw;
+    long long hi = (long long)s + bw;
+    unsigned int vbs = (unsigned int)(lo > 0 ? lo : 0);  // max(0, s - bw)
+    // min(N, s + bw); a negative value cannot be packed: clamp to -1 -> flagged as bad band
+    unsigned int vbe = (unsigned int)((hi < N ? (hi < -1 ? -1 : hi) : N) + 1);
+    unsigned long long tag = ((unsigned long long)(j + 1)) << 32;
+    atomicMax(&tbs[ri], tag | vbs);
+    atomicMax(&tbe[ri], tag | vbe);
+  }
+  __syncthreads();
+  // the row table stores bands as int32 inside RowParam; first write raw per-base bands into
+  // the scratch (low words), scanning in chunks of 64 with a carry
+  int carry = 0;
+  for (int base = 0; base <= R; base += 64) {
+    int j = base + lane;
+    int v = 0;
+    if (j <= R) {
+      unsigned long long w = tbs[j];
+      v = (w >> 32) ? (int)(unsigned int)(w & 0xffffffffu) : 0;
+    }
+    v = max(wave_scan_max(v, lane), carry);
+    carry = __shfl(v, 63, 64);
+    if (j <= R) tbs[j] = (unsigned long long)(unsigned int)v;
+  }
+  carry = N;
+  for (int base = (R / 64) * 64; base >= 0; base -= 64) {
+    int j = base + lane;
+    int v = N;
+    if (j <= R) {
+      unsigned long long w = tbe[j];
+      v = (w >> 32) ? (int)(unsigned int)(w & 0xffffffffu) - 1 : N;
+    } else {
+      v = 0x7fffffff;
+    }
+    v = min(wave_scan_min_rev(v, lane), carry);
+    carry = __shfl(v, 0, 64);
+    if (j <= R) tbe[j] = (unsigned long long)(unsigned int)v;
+  }
+  __syncthreads();
+
+}
+
 // bandtmp: per read 2*(R+1) u64 scratch words at bandtmp[2*(ref_off+j) ...]
 __global__ __launch_bounds__(64) void plan_kernel(DeviceModel dm, BatchArgs a, int mode,
                                                   double log_p_in, ReadMeta *metas, RowParam *rows,
@@ -112,56 +166,9 @@ __global__ __launch_bounds__(64) void plan_kernel(DeviceModel dm, BatchArgs a, i
     return;
   }
 
-  // --- bands: "later anchor overwrites", then prefix-max / suffix-min -------------------------
-  // scratch word = (anchor ordinal + 1) << 32 | payload ; atomicMax keeps the last anchor
   unsigned long long *tbs = bandtmp + 2 * (r0 + rd);
   unsigned long long *tbe = tbs + (R + 1);
-  for (int j = lane; j <= R; j += 64) {
-    tbs[j] = 0ull;
-    tbe[j] = 0ull;
-  }
-  __syncthreads();
-  for (int j = lane; j < A; j += 64) {
-    int s = anc[2 * j], ri = anc[2 * j + 1];
-    long long lo = (long long)s - bw;
-    long long hi = (long long)s + bw;
-    unsigned int vbs = (unsigned int)(lo > 0 ? lo : 0);  // max(0, s - bw)
-    // min(N, s + bw); a negative value cannot be packed: clamp to -1 -> flagged as bad band
-    unsigned int vbe = (unsigned int)((hi < N ? (hi < -1 ? -1 : hi) : N) + 1);
-    unsigned long long tag = ((unsigned long long)(j + 1)) << 32;
-    atomicMax(&tbs[ri], tag | vbs);
-    atomicMax(&tbe[ri], tag | vbe);
-  }
-  __syncthreads();
-  // the row table stores bands as int32 inside RowParam; first write raw per-base bands into
-  // the scratch (low words), scanning in chunks of 64 with a carry
-  int carry = 0;
-  for (int base = 0; base <= R; base += 64) {
-    int j = base + lane;
-    int v = 0;
-    if (j <= R) {
-      unsigned long long w = tbs[j];
-      v = (w >> 32) ? (int)(unsigned int)(w & 0xffffffffu) : 0;
-    }
-    v = max(wave_scan_max(v, lane), carry);
-    carry = __shfl(v, 63, 64);
-    if (j <= R) tbs[j] = (unsigned long long)(unsigned int)v;
-  }
-  carry = N;
-  for (int base = (R / 64) * 64; base >= 0; base -= 64) {
-    int j = base + lane;
-    int v = N;
-    if (j <= R) {
-      unsigned long long w = tbe[j];
-      v = (w >> 32) ? (int)(unsigned int)(w & 0xffffffffu) - 1 : N;
-    } else {
-      v = 0x7fffffff;
-    }
-    v = min(wave_scan_min_rev(v, lane), carry);
-    carry = __shfl(v, 0, 64);
-    if (j <= R) tbe[j] = (unsigned long long)(unsigned int)v;
-  }
-  __syncthreads();
+  plan_bands(anc, A, R, N, bw, tbs, tbe, lane);
 
   // --- row table -----------------------------------------------------------------------------
   RowParam *rp = rows + m.row_off;
@@ -247,6 +254,152 @@ __global__ __launch_bounds__(64) void plan_kernel(DeviceModel dm, BatchArgs a, i
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// planner for estimate_log_likelihoods (dtw.cpp:37-131): bands, row-store offsets and the fused
+// per-position descriptors of the prefix sweep and of the (mirrored) suffix sweep.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void gauss_params(const DeviceModel &dm, int64_t id, double *mean,
+                                             double *ac, double *mc) {
+  *mean = dm.mean[id];
+  *ac = dm.ac[id];
+  *mc = dm.mc[id];
+}
+
+__global__ __launch_bounds__(64) void plan_ell_kernel(DeviceModel dm, BatchArgs a, int wobbling,
+                                                      EllPlan pl, unsigned long long *bandtmp,
+                                                      PlanTotals *totals) {
+  const int rd = blockIdx.x;
+  const int lane = threadIdx.x;
+  if (rd >= a.n_reads) return;
+  const int64_t s0 = a.sig_off[rd], r0 = a.ref_off[rd], a0 = a.anc_off[rd];
+  const int64_t N64 = a.sig_off[rd + 1] - s0;
+  const int64_t R64 = a.ref_off[rd + 1] - r0;
+  const int A = (int)(a.anc_off[rd + 1] - a0);
+  const int nb = (int)(a.cb_off[rd + 1] - a.cb_off[rd]);
+  const int na = (int)(a.ca_off[rd + 1] - a.ca_off[rd]);
+  const int32_t *ref = a.reference + r0;
+  const int32_t *cb = a.ctx_before + a.cb_off[rd];
+  const int32_t *ca = a.ctx_after + a.ca_off[rd];
+  const int32_t *anc = a.anchors + 2 * a0;
+  const int N = (int)N64, R = (int)R64;
+
+  ReadMeta m;
+  m.sig_off = s0;
+  m.ref_off = r0;
+  m.row_off = r0;
+  m.N = N;
+  m.R = R;
+  m.T = R;
+  m.c = 1;
+  m.t_min = 0;
+  m.n_steps = 0;
+  m.status = NVK_READ_OK;
+  m.pad = 0;
+  m.cells = 0;
+
+  int bad = (R < 1 || N < 1 || N64 > 0x3fffffff || R64 > 0x1fffffff) ? 1 : 0;
+  for (int j = lane; j < A && !bad; j += 64) {
+    int si = anc[2 * j], ri = anc[2 * j + 1];
+    if (ri < 0 || ri > R || si < -(1 << 30) || si > (1 << 30)) bad = 1;
+  }
+  for (int j = lane; j < R && !bad; j += 64)
+    if (ref[j] < 0 || ref[j] >= dm.alphabet) bad = 1;
+  bad = __any(bad);
+  if (bad) {
+    m.status = NVK_READ_BAD_INPUT;
+    if (lane == 0) pl.metas[rd] = m;
+    return;
+  }
+  unsigned long long *tbs = bandtmp + 2 * (r0 + rd);
+  unsigned long long *tbe = tbs + (R + 1);
+  plan_bands(anc, A, R, N, a.bandwidth, tbs, tbe, lane);
+
+  int32_t *bs = pl.bs + r0 + rd, *be = pl.be + r0 + rd, *rowoff = pl.rowoff + r0 + rd;
+  int badband = 0;
+  int carry = 0;
+  for (int base = 0; base <= R; base += 64) {
+    int r = base + lane;
+    int w = 0;
+    if (r <= R) {
+      int b0 = (int)(unsigned int)tbs[r], b1 = (int)(unsigned int)tbe[r];
+      bs[r] = b0;
+      be[r] = b1;
+      w = b1 - b0 + 1;
+      if (w < 1) {
+        badband = 1;
+        w = 0;
+      }
+    }
+    // exclusive prefix sum of the row widths
+    int inc = w;
+    for (int d = 1; d < 64; d <<= 1) {
+      int o = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += o;
+    }
+    if (r <= R) rowoff[r] = carry + inc - w;
+    carry += __shfl(inc, 63, 64);
+  }
+  badband = __any(badband);
+  const int cells = carry;
+  __syncthreads();
+
+  FusedParam *fw = pl.fwd + r0, *rv = pl.rev + r0;
+  for (int j = lane; j < R; j += 64) {
+    FusedParam f;
+    f.has_wob = (j > 0 && wobbling) ? 1 : 0;
+    f.a_mean = f.a_ac = f.a_mc = 0.0;
+    if (f.has_wob) gauss_params(dm, kmer_id(dm, ref, R, cb, nb, ca, na, j - 1), &f.a_mean, &f.a_ac, &f.a_mc);
+    gauss_params(dm, kmer_id(dm, ref, R, cb, nb, ca, na, j), &f.b_mean, &f.b_ac, &f.b_mc);
+    f.wbs = bs[j];
+    f.wbe = be[j];
+    f.ebs = bs[j + 1];
+    f.ebe = be[j + 1];
+    f.store_off = rowoff[j + 1];
+    f.pad0 = f.pad1 = 0;
+    fw[j] = f;
+    // suffix sweep, lane jj handles boundary i = R - jj: input suffix[i] (band i), wobble with the
+    // mixture of k-mers (i, i-1), emit with k-mer i-1 into suffix[i-1] (band i-1); mirrored i' = N - i
+    const int jj = j, i = R - jj;
+    FusedParam g;
+    g.has_wob = (i < R && wobbling) ? 1 : 0;
+    g.a_mean = g.a_ac = g.a_mc = 0.0;
+    if (g.has_wob) gauss_params(dm, kmer_id(dm, ref, R, cb, nb, ca, na, i), &g.a_mean, &g.a_ac, &g.a_mc);
+    gauss_params(dm, kmer_id(dm, ref, R, cb, nb, ca, na, i - 1), &g.b_mean, &g.b_ac, &g.b_mc);
+    g.wbs = N - be[i];
+    g.wbe = N - bs[i];
+    g.ebs = N - be[i - 1];
+    g.ebe = N - bs[i - 1];
+    g.store_off = rowoff[i - 1];
+    g.pad0 = g.pad1 = 0;
+    rv[jj] = g;
+  }
+  __syncthreads();
+  int cneed = 1;
+  for (int j = 64 + lane; j < R; j += 64) {
+    int d1 = fw[j - 64].ebe - fw[j].wbs;
+    int d2 = rv[j - 64].ebe - rv[j].wbs;
+    int d = max(d1, d2);
+    if (d >= 0) cneed = max(cneed, d / 64 + 1);
+  }
+  int c = wave_max(cneed);
+  if (lane == 0) {
+    m.c = c;
+    m.cells = cells;
+    m.n_steps = N + 1 + c * R;
+    if (badband) m.status = NVK_READ_BAD_BAND;
+    pl.metas[rd] = m;
+    if (!badband) {
+      atomicMax(&totals->max_steps, m.n_steps);
+      atomicMax(&totals->max_c, c);
+      atomicMax(&totals->max_T, R);
+      atomicMax(&totals->max_W, cells);
+      atomicAdd(&totals->cells, (unsigned long long)cells);
+      atomicAdd(&totals->steps, (unsigned long long)m.n_steps);
+    }
+  }
+}
+
 __global__ void expected_kernel(DeviceModel dm, int64_t n_reads, int64_t total_ref,
                                 const int32_t *reference, const int64_t *ref_off,
                                 const int32_t *cbs, const int64_t *cb_off, const int32_t *cas,
@@ -281,6 +434,19 @@ int launch_plan(nvk_ctx *ctx, const DeviceModel &dm, const BatchArgs &a, int mod
     const double log_p_in = log(0.01);
     hipLaunchKernelGGL(plan_kernel, dim3((unsigned)a.n_reads), dim3(64), 0, ctx->stream, dm, a, mode,
                        log_p_in, metas, rows, bandtmp, totals);
+  }
+  NVK_HIP(hipGetLastError());
+  return NVK_OK;
+}
+
+int launch_plan_ell(nvk_ctx *ctx, const DeviceModel &dm, const BatchArgs &a, int wobbling,
+                    const EllPlan &pl, unsigned long long *bandtmp, PlanTotals *totals) {
+  NVK_HIP(hipMemsetAsync(totals, 0, sizeof(PlanTotals), ctx->stream));
+  if (a.n_reads == 0) return NVK_OK;
+  {
+    TimerScope ts(ctx, NVK_K_PLAN);
+    hipLaunchKernelGGL(plan_ell_kernel, dim3((unsigned)a.n_reads), dim3(64), 0, ctx->stream, dm, a,
+                       wobbling, pl, bandtmp, totals);
   }
   NVK_HIP(hipGetLastError());
   return NVK_OK;

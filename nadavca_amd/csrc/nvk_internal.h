@@ -20,6 +20,21 @@ struct __attribute__((aligned(16))) RowParam {
 };
 static_assert(sizeof(RowParam) == 48, "RowParam layout");
 
+// estimate_log_likelihoods: one entry per base position j of a sweep, describing the FUSED pair
+// of reference rows handled by one lane: the wobble row (mixture density, min event length 0,
+// dtw.cpp:53-59 / 70-76) on band "w", then the emitting row (Gaussian, dtw.cpp:60-63 / 77-80)
+// on band "e".  Coordinates are those of the sweep (mirrored for the suffix sweep).
+struct __attribute__((aligned(16))) FusedParam {
+  double a_mean, a_ac, a_mc;  // the mixture's other component
+  double b_mean, b_ac, b_mc;  // the emitting Gaussian (also a mixture component)
+  int32_t wbs, wbe;           // band of the wobble row == band of the predecessor row
+  int32_t ebs, ebe;           // band of the emitting row
+  int32_t has_wob;            // 0: no wobble row, the predecessor feeds the emitting row directly
+  int32_t store_off;          // first cell of the emitting row in the slot's row store
+  int32_t pad0, pad1;
+};
+static_assert(sizeof(FusedParam) == 80, "FusedParam layout");
+
 struct ReadMeta {
   int64_t sig_off;   // first sample of the read's signal slice
   int64_t row_off;   // first RowParam of the read
@@ -120,6 +135,17 @@ int launch_plan(nvk_ctx *ctx, const DeviceModel &dm, const BatchArgs &a, int mod
 int launch_align(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadMeta *metas,
                  const RowParam *rows, const PlanTotals &tot, int32_t *out_events,
                  int32_t *out_status);
+struct EllPlan {
+  ReadMeta *metas;
+  FusedParam *fwd;       // [total_ref] prefix-sweep descriptors, position order
+  FusedParam *rev;       // [total_ref] suffix-sweep descriptors, mirrored coordinates
+  int32_t *bs, *be;      // [total_ref + n] bands per boundary row
+  int32_t *rowoff;       // [total_ref + n] offset of each boundary row in the row store
+};
+int launch_plan_ell(nvk_ctx *ctx, const DeviceModel &dm, const BatchArgs &a, int wobbling,
+                    const EllPlan &pl, unsigned long long *bandtmp, PlanTotals *totals);
+int launch_ell(nvk_ctx *ctx, const DeviceModel &dm, const BatchArgs &a, int wobbling,
+               const EllPlan &pl, const PlanTotals &tot, double *out_ll, int32_t *out_status);
 int launch_expected(nvk_ctx *ctx, const DeviceModel &dm, int64_t n_reads, int64_t total_ref,
                     const int32_t *reference, const int64_t *ref_off, const int32_t *cb,
                     const int64_t *cb_off, const int32_t *ca, const int64_t *ca_off, double *out);

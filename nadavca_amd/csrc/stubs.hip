@@ -2,16 +2,6 @@
 // They fail loudly (no CPU fallback); each is removed from here when its kernel lands.
 #include "nvk_internal.h"
 
-#ifndef NVK_HAVE_ELL
-extern "C" int nvk_estimate_log_likelihoods_batch(nvk_model *, int64_t, const double *, const int64_t *, const int32_t *, const int64_t *, const int32_t *, const int64_t *, const int32_t *, const int64_t *, const int32_t *, const int64_t *, int, int, int, double *, int32_t *) {
-  nvk_set_error("estimate_log_likelihoods kernels not built into this library");
-  return NVK_ERR_UNSUPPORTED;
-}
-extern "C" int nvk_estimate_log_likelihoods_batch_dev(nvk_model *, int64_t, int64_t, int64_t, int64_t, const double *, const int64_t *, const int32_t *, const int64_t *, const int32_t *, const int64_t *, const int32_t *, const int64_t *, const int32_t *, const int64_t *, int, int, int, double *, int32_t *) {
-  nvk_set_error("estimate_log_likelihoods kernels not built into this library");
-  return NVK_ERR_UNSUPPORTED;
-}
-#endif
 #ifndef NVK_HAVE_CONSENSUS
 extern "C" int nvk_consensus_accumulate_dev(nvk_ctx *, int64_t, int64_t, int, const double *, const int32_t *, const int64_t *, const int64_t *, const int32_t *, const int32_t *, double, int64_t, double *, int64_t *) {
   nvk_set_error("consensus kernels not built into this library");
