@@ -168,12 +168,28 @@ int nvk_consensus_accumulate_dev(nvk_ctx *ctx, int64_t n_reads, int64_t total_re
                                  double normalization_event_length, int64_t ref_len, double *acc,
                                  int64_t *coverage);
 
+/* host-pointer flavour of the above (acc / coverage are read, accumulated into, written back) */
+int nvk_consensus_accumulate(nvk_ctx *ctx, int64_t n_reads, int alphabet, const double *ll,
+                             const int32_t *reference, const int64_t *ref_off,
+                             const int64_t *chunk_start, const int32_t *reverse,
+                             const int32_t *status, double normalization_event_length,
+                             int64_t ref_len, double *acc, int64_t *coverage);
+
 /* replaces ProbabilityEstimator._compute_posterior / _corrected_priors
  * (estimator.py:123-156) for one group of `len` consecutive positions.
  * ll f64[len*alphabet], reference i32[len] (numerical bases), out f64[len*alphabet];
  * device pointers. */
 int nvk_posterior_dev(nvk_ctx *ctx, int64_t len, int alphabet, int k, double snp_prior,
                       const double *ll, const int32_t *reference, double *out);
+
+/* the same for n_segments independent groups laid end to end: segment s covers positions
+ * [seg_off[s], seg_off[s+1]); context windows never cross a segment border */
+int nvk_posterior_segments_dev(nvk_ctx *ctx, int64_t len, int64_t n_segments, const int64_t *seg_off,
+                               int alphabet, int k, double snp_prior, const double *ll,
+                               const int32_t *reference, double *out);
+/* host-pointer flavour; seg_off may be NULL for a single group */
+int nvk_posterior(nvk_ctx *ctx, int64_t len, int64_t n_segments, const int64_t *seg_off, int alphabet,
+                  int k, double snp_prior, const double *ll, const int32_t *reference, double *out);
 
 #ifdef __cplusplus
 }

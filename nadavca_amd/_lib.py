@@ -54,6 +54,9 @@ SIGNATURES = {
     'nvk_estimate_log_likelihoods_batch_dev': (_int, [_vp, _i64, _i64, _i64, _i64] + [_vp] * 10 + [_int, _int, _int, _vp, _vp]),
     'nvk_consensus_accumulate_dev': (_int, [_vp, _i64, _i64, _int] + [_vp] * 6 + [_dbl, _i64, _vp, _vp]),
     'nvk_posterior_dev': (_int, [_vp, _i64, _int, _int, _dbl, _vp, _vp, _vp]),
+    'nvk_consensus_accumulate': (_int, [_vp, _i64, _int] + [_vp] * 6 + [_dbl, _i64, _vp, _vp]),
+    'nvk_posterior_segments_dev': (_int, [_vp, _i64, _i64, _vp, _int, _int, _dbl, _vp, _vp, _vp]),
+    'nvk_posterior': (_int, [_vp, _i64, _i64, _vp, _int, _int, _dbl, _vp, _vp, _vp]),
 }
 
 _lib = None

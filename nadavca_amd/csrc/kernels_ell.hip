@@ -433,7 +433,9 @@ __global__ __launch_bounds__(64) void ell_kernel(EllArgs g) {
       }
       if (is_fin) out[(size_t)p * alpha + b] = xm::to_log(acc);
     }
-    if (lane == 0) g.out_status[rd] = NVK_READ_OK;
+    // a read without any valid path has likelihood zero everywhere (the reference returns an
+    // all -inf matrix, which its estimator then turns into NaN): report it per read instead
+    if (lane == 0) g.out_status[rd] = (no_snp == -INFINITY) ? NVK_READ_NO_PATH : NVK_READ_OK;
   }
 }
 

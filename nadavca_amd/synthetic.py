@@ -126,3 +126,93 @@ WORKLOADS = {
 def env_int(name, default):
     v = os.environ.get(name)
     return int(v) if v else default
+
+
+# ------------------------------------------------------------------------------------------------
+# Read-level synthetic data: reads sampled from a genome on both strands + an aligner that returns
+# the true base mapping (stands in for BWA, which does not exist offline)
+# ------------------------------------------------------------------------------------------------
+_BASES = np.array(['A', 'C', 'G', 'T'])
+_COMPLEMENT_NUM = np.array([3, 2, 1, 0])
+
+
+def make_genome(length, seed):
+    """iid uniform ACGT reference as an array of single characters (Genome.bases layout)."""
+    rng = np.random.default_rng(seed)
+    return _BASES[rng.integers(0, 4, length)]
+
+
+def make_read_spec(rng, genome_num, model, index, length=400, spread=40, dwell=(3, 17), noise=0.35,
+                   anchor_density=0.75, jitter=20, trim=3, substitution_rate=0.0, raw_scale=12.0,
+                   raw_shift=90.0):
+    """Plain-data description of one simulated read (no classes): raw signal, basecalled sequence,
+    base->sample map, and the true base mapping in the shape ``_get_base_alignment`` returns."""
+    k, central, alphabet, mean, sigma = model
+    G = genome_num.size
+    L = int(min(G, length + rng.integers(-spread, spread + 1)))
+    g0 = int(rng.integers(0, G - L + 1))
+    reverse = bool(index % 2)
+    seg = genome_num[g0:g0 + L]
+    oriented = _COMPLEMENT_NUM[seg][::-1] if reverse else seg.copy()   # read orientation
+    seq = oriented.copy()
+    subs = rng.random(L) < substitution_rate
+    seq[subs] = (seq[subs] + rng.integers(1, 4, int(subs.sum()))) % 4
+    ids = kmer_ids(seq, 0, L, k, central, alphabet)
+    dw = rng.integers(dwell[0], dwell[1] + 1, L)
+    starts = np.concatenate([[0], np.cumsum(dw)])
+    x = np.clip(np.repeat(mean[ids], dw) + rng.normal(0.0, noise, int(starts[-1])), -5.0, 5.0)
+    raw = raw_scale * x + raw_shift
+    # anchors: matched, thinned, with a jittered (but monotone) base->sample map
+    matched = np.nonzero(~subs)[0]
+    cand = matched[(matched >= trim) & (matched < L - trim)]
+    keep = cand[rng.random(cand.size) < anchor_density]
+    pos = np.clip(starts[keep] + rng.integers(-jitter, jitter + 1, keep.size), 0, int(starts[-1]) - 1)
+    pos = np.maximum.accumulate(pos)
+    seq_to_sig = {int(b): int(p) for b, p in zip(keep, pos)}
+    # base mapping rows (read index, reference index in the read's orientation), alignment.py:128-134
+    ref_idx = (G - 1 - (g0 + L - 1 - matched)) if reverse else (g0 + matched)
+    base_mapping = np.stack([matched, ref_idx], axis=1).astype(int)
+    return dict(raw_signal=raw, sequence=_BASES[seq], sequence_to_signal_mapping=seq_to_sig,
+                base_mapping=base_mapping, reverse=reverse, g0=g0, length=L, true_starts=starts)
+
+
+def make_read_specs(n, genome, model, seed=0, **kw):
+    genome_num = np.array([{'A': 0, 'C': 1, 'G': 2, 'T': 3}[b] for b in genome])
+    return [make_read_spec(np.random.default_rng([seed, i]), genome_num, model, i, **kw) for i in range(n)]
+
+
+def reads_from_specs(specs, read_class=None):
+    """Instantiate ``Read`` objects (this package's class by default) from plain specs."""
+    if read_class is None:
+        from .read import Read as read_class
+    out = []
+    for s in specs:
+        r = read_class()
+        r.raw_signal = np.array(s['raw_signal'])
+        r.sequence = np.array(s['sequence'])
+        r.sequence_to_signal_mapping = dict(s['sequence_to_signal_mapping'])
+        r._spec = s
+        out.append(r)
+    return out
+
+
+def make_synthetic_aligner(base_class, reference):
+    """Subclass ``base_class`` (an ApproximateAligner) so that ``_get_base_alignment`` returns the
+    simulated truth attached to each read; everything downstream (convert_mapping,
+    get_signal_alignment) is the base class's own code."""
+
+    class SyntheticAligner(base_class):
+        def __init__(self, reference):
+            self.reference = reference
+            self.references_dict = None
+            self.reference_filename = None
+            self.bwa_executable = None
+            self.bwapy_aligner = None
+
+        def _get_base_alignment(self, read):
+            s = read._spec
+            if len(s['base_mapping']) == 0:
+                return None
+            return np.array(s['base_mapping'], dtype=int), s['reverse'], 'synthetic'
+
+    return SyntheticAligner(reference)
