@@ -182,25 +182,40 @@ class ProbabilityEstimator:
                                      _ptr(ref), _ptr(out)), 'nvk_posterior')
         return out
 
-    def estimate_probabilities(self, reference, reads):
-        """Consensus over all reads (estimator.py:199-236) -> list of Chunk(start, end, posterior,
-        coverage), one per group of overlapping reads."""
-        live, batch, ll, status = self._log_likelihood_batch(reference, reads)
-        keep = [j for j, p in enumerate(live) if status[j] == dtw.READ_OK]
-        if not keep:
-            return []
-        ranges = sorted((live[j].apx.reference_range for j in keep))
+    @staticmethod
+    def group_ranges(ranges):
+        """Merge sorted (start, end) chunk intervals into groups while next.start < current_end;
+        touching chunks do not merge (estimator.py:205-220)."""
+        ranges = sorted(ranges)
         groups, cur_s, cur_e = [], None, None
         for idx, (s, e) in enumerate(ranges):
             if cur_s is None:
                 cur_s, cur_e = s, e
             cur_e = max(cur_e, e)
-            if idx + 1 >= len(ranges) or ranges[idx + 1][0] >= cur_e:  # touching chunks do not merge
+            if idx + 1 >= len(ranges) or ranges[idx + 1][0] >= cur_e:
                 groups.append((cur_s, cur_e))
                 cur_s = cur_e = None
+        return groups
+
+    def local_consensus(self, reference, reads):
+        """This process's share of the consensus: per-position sums of the normalised,
+        strand-corrected log-likelihoods of ``reads`` over the whole reference, the coverage, and
+        the chunk intervals (estimator.py:199-231).  -> (acc (L,4) f64, cov (L,) i64, ranges)."""
+        alpha = self.kmer_model.alphabet_size
+        live, batch, ll, status = self._log_likelihood_batch(reference, reads)
+        keep = [j for j, p in enumerate(live) if status[j] == dtw.READ_OK]
+        if not keep:
+            return (numpy.zeros((len(reference), alpha)), numpy.zeros(len(reference), dtype=numpy.int64), [])
         chunk_start = [p.apx.reference_range[0] for p in live]
         acc, cov = self._accumulate(live, batch, ll, status, chunk_start, len(reference))
-        # posterior of all groups in one launch: groups laid end to end
+        return acc, cov, [tuple(int(v) for v in live[j].apx.reference_range) for j in keep]
+
+    def posterior_groups(self, reference, acc, cov, ranges):
+        """Group the chunk intervals and turn the summed log-likelihoods into posteriors
+        (estimator.py:205-235): all groups in one launch, laid end to end."""
+        groups = self.group_ranges(ranges)
+        if not groups:
+            return []
         seg_off = numpy.zeros(len(groups) + 1, dtype=numpy.int64)
         numpy.cumsum([e - s for s, e in groups], out=seg_off[1:])
         ll_cat = numpy.concatenate([acc[s:e] for s, e in groups])
@@ -208,6 +223,12 @@ class ProbabilityEstimator:
         post = self._posterior(ll_cat, ref_cat, seg_off)
         return [Chunk(s, e, post[seg_off[g]:seg_off[g + 1]], cov[s:e].copy())
                 for g, (s, e) in enumerate(groups)]
+
+    def estimate_probabilities(self, reference, reads):
+        """Consensus over all reads (estimator.py:199-236) -> list of Chunk(start, end, posterior,
+        coverage), one per group of overlapping reads."""
+        acc, cov, ranges = self.local_consensus(reference, reads)
+        return self.posterior_groups(reference, acc, cov, ranges)
 
     def estimate_probabilities_independent(self, reference, reads):
         """``[estimate_probabilities(reference, [read])[0] for read in reads]`` in batched form
