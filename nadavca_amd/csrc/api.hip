@@ -4,6 +4,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -31,6 +32,7 @@ int nvk_ws_reserve(nvk_ctx *ctx, int which, size_t bytes) {
   if (bytes <= ctx->ws_bytes[which]) return NVK_OK;
   if (ctx->ws[which]) {
     NVK_HIP(hipStreamSynchronize(ctx->stream));
+    NVK_HIP(hipStreamSynchronize(ctx->stream2));
     NVK_HIP(hipFree(ctx->ws[which]));
     ctx->ws[which] = nullptr;
     ctx->ws_bytes[which] = 0;
@@ -91,8 +93,10 @@ extern "C" int nvk_ctx_create(int device, nvk_ctx **out) {
     return NVK_ERR_HIP;
   }
   c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  if (hipStreamCreate(&c->stream) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
-      hipEventCreate(&c->ev1) != hipSuccess) {
+  if (hipStreamCreate(&c->stream) != hipSuccess || hipStreamCreate(&c->stream2) != hipSuccess ||
+      hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
     delete c;
     nvk_set_error("stream/event creation failed");
     return NVK_ERR_HIP;
@@ -105,10 +109,14 @@ extern "C" void nvk_ctx_destroy(nvk_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  for (int i = 0; i < 8; i++)
+  (void)hipStreamSynchronize(ctx->stream2);
+  for (int i = 0; i < WS_COUNT; i++)
     if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
   (void)hipEventDestroy(ctx->ev0);
   (void)hipEventDestroy(ctx->ev1);
+  (void)hipEventDestroy(ctx->ev_fork);
+  (void)hipEventDestroy(ctx->ev_join);
+  (void)hipStreamDestroy(ctx->stream2);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -454,11 +462,41 @@ extern "C" int nvk_refine_alignment_batch_dev(
   a.bandwidth = bandwidth;
   a.mel = min_event_length;
   PlanTotals tot;
-  rc = plan_batch(model, a, model_transitions ? PLAN_ALIGN_TRANS : PLAN_ALIGN_PLAIN, 0, tot);
-  if (rc) return rc;
-  rc = launch_align(ctx, a, model_transitions ? 1 : 0, (const ReadMeta *)ctx->ws[WS_META],
-                    (const RowParam *)ctx->ws[WS_ROWS], tot, out_events, out_status);
-  if (rc) return rc;
+  // two implementations of the same operator with identical results: the one-row-per-lane,
+  // one-read-per-wave kernel (kernels_align.hip) is the default; the fused-lane, two-reads-per-wave
+  // kernel (kernels_align2.hip) is selected with NADAVCA_ALIGN_KERNEL=2 (both are parity-tested)
+  const char *force = getenv("NADAVCA_ALIGN_KERNEL");
+  bool use_v1 = !(force && force[0] == '2');
+  if (!use_v1) {
+    const int64_t n = n_reads, nrow = total_ref + n;
+    if ((rc = nvk_ws_reserve(ctx, WS_META, (size_t)(n + 1) * sizeof(ReadMeta) + 64))) return rc;
+    if ((rc = nvk_ws_reserve(ctx, WS_ROWS, (size_t)(nrow + 1) * sizeof(AlignLane)))) return rc;
+    if ((rc = nvk_ws_reserve(ctx, WS_ROWS2, (size_t)(nrow + 1) * sizeof(AlignLane)))) return rc;
+    if ((rc = nvk_ws_reserve(ctx, WS_BANDTMP, (size_t)(2 * nrow + 2) * 8))) return rc;
+    if ((rc = nvk_ws_reserve(ctx, WS_MISC, 256))) return rc;
+    Align2Plan pl;
+    pl.metas = (ReadMeta *)ctx->ws[WS_META];
+    pl.fwd = (AlignLane *)ctx->ws[WS_ROWS];
+    pl.rev = (AlignLane *)ctx->ws[WS_ROWS2];
+    PlanTotals *d_tot = (PlanTotals *)((char *)ctx->ws[WS_MISC] + 64);
+    rc = launch_plan_align2(ctx, model->dm, a, model_transitions ? 1 : 0, ALIGN2_C_CAP, pl,
+                            (unsigned long long *)ctx->ws[WS_BANDTMP], d_tot);
+    if (rc) return rc;
+    NVK_HIP(hipMemcpyAsync(&tot, d_tot, sizeof(PlanTotals), hipMemcpyDeviceToHost, ctx->stream));
+    NVK_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->last_cells = (int64_t)tot.cells;
+    ctx->last_steps = (int64_t)tot.steps;
+    rc = launch_align2(ctx, a, model_transitions ? 1 : 0, pl, tot, out_events, out_status);
+    if (rc == NVK_ERR_UNSUPPORTED) use_v1 = true;  // band too wide for the paired layout
+    else if (rc) return rc;
+  }
+  if (use_v1) {
+    rc = plan_batch(model, a, model_transitions ? PLAN_ALIGN_TRANS : PLAN_ALIGN_PLAIN, 0, tot);
+    if (rc) return rc;
+    rc = launch_align(ctx, a, model_transitions ? 1 : 0, (const ReadMeta *)ctx->ws[WS_META],
+                      (const RowParam *)ctx->ws[WS_ROWS], tot, out_events, out_status);
+    if (rc) return rc;
+  }
   NVK_HIP(hipStreamSynchronize(ctx->stream));
   return NVK_OK;
 }

@@ -58,6 +58,7 @@ struct AlignArgs {
   int H;   // history ring slots (> c + mel; need not be a power of two)
   int SR;  // signal ring samples (pow2 >= 64*c + CH)
   int transitions;
+  int wide, c_cap;  // class served by this launch: skew <= c_cap (wide = 0) or above (wide = 1)
   int32_t *out_events;
   int32_t *out_status;
 };
@@ -113,9 +114,10 @@ __global__ __launch_bounds__(64) void align_kernel(AlignArgs g) {
     if (rd >= g.n_reads) break;
     const ReadMeta m = g.metas[rd];
     if (m.status != NVK_READ_OK) {
-      if (lane == 0) g.out_status[rd] = m.status;
+      if (lane == 0 && !g.wide) g.out_status[rd] = m.status;
       continue;
     }
+    if ((m.c > g.c_cap) != (g.wide != 0)) continue;  // served by the other launch
     const int T = __builtin_amdgcn_readfirstlane(m.T);
     const int N = __builtin_amdgcn_readfirstlane(m.N);
     const int c = __builtin_amdgcn_readfirstlane(m.c);
@@ -441,72 +443,85 @@ int launch_align(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadMe
     nvk_set_error("min_event_length %d outside the compiled range 0..4", mel);
     return NVK_ERR_UNSUPPORTED;
   }
-  int c = tot.max_c < 1 ? 1 : tot.max_c;
-  int H = c + mel + 1;  // the slot read is c+mel steps old; one more so it is not yet overwritten
-  int SR = 256;
-  while (SR < 64 * c + CH) SR <<= 1;
-  size_t lds = (size_t)SR * 8 + (size_t)TABN * sizeof(RowParam) + 2 * (size_t)H * 64 * 12 + 16;
-  if (lds > 160 * 1024) {
-    nvk_set_error("band too wide for one wave per read: skew %d needs %zu bytes of LDS", c, lds);
-    return NVK_ERR_UNSUPPORTED;
+  const int max_c = tot.max_c < 1 ? 1 : tot.max_c;
+  const int max_steps = tot.max_steps < 1 ? 1 : tot.max_steps;
+  // Two classes, so that a few wide-band outliers do not size everyone's LDS (occupancy is what
+  // this latency-bound kernel lives on); the small wide class runs concurrently on a side stream.
+  TimerScope ts(ctx, NVK_K_ALIGN);
+  NVK_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+  NVK_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+  for (int wide = 1; wide >= 0; wide--) {
+    const int64_t n_class = wide ? tot.n_wide : a.n_reads - tot.n_wide;
+    if (n_class <= 0) continue;
+    hipStream_t st = wide ? ctx->stream2 : ctx->stream;
+    const int c = wide ? max_c : (max_c < ALIGN1_C_CAP ? max_c : ALIGN1_C_CAP);
+    const int H = c + mel + 1;  // the slot read is c+mel steps old; one more so it is not yet overwritten
+    int SR = 256;
+    while (SR < 64 * c + CH) SR <<= 1;
+    size_t lds = (size_t)SR * 8 + (size_t)TABN * sizeof(RowParam) + 2 * (size_t)H * 64 * 12 + 16;
+    if (lds > 160 * 1024) {
+      nvk_set_error("band too wide for one wave per read: skew %d needs %zu bytes of LDS", c, lds);
+      return NVK_ERR_UNSUPPORTED;
+    }
+    // waves resident per CU are bounded by LDS; more than 4 per SIMD buys nothing here
+    int per_cu = (int)((160 * 1024) / lds);
+    if (per_cu > 16) per_cu = 16;
+    if (per_cu < 1) per_cu = 1;
+    int64_t slots = ctx->slots_override > 0 ? ctx->slots_override : (int64_t)ctx->num_cus * per_cu;
+    if (slots > n_class) slots = n_class;
+    // per-slot workspace, padded by 2*PF steps so that prefetches past the end stay in bounds
+    const int64_t spill_stride = ((int64_t)max_steps + 2 * PF) * 64;
+    const int64_t bp_stride = (int64_t)((max_steps + 31) / 32 + 1) * 64;
+    const int64_t cap = (int64_t)48 << 30;
+    while (slots > 1 && slots * spill_stride * 12 > cap) slots /= 2;
+    const int wsm = wide ? WS_SPILL_B : WS_SPILL, wse = wide ? WS_STAGE_B : WS_STAGE,
+              wsb = wide ? WS_BP_B : WS_BP;
+    int rc = nvk_ws_reserve(ctx, wsm, (size_t)slots * spill_stride * 8);
+    if (rc) return rc;
+    rc = nvk_ws_reserve(ctx, wse, (size_t)slots * spill_stride * 4);
+    if (rc) return rc;
+    rc = nvk_ws_reserve(ctx, wsb, (size_t)slots * bp_stride * 4);
+    if (rc) return rc;
+    rc = nvk_ws_reserve(ctx, WS_MISC, 256);
+    if (rc) return rc;
+    int *counter = (int *)ctx->ws[WS_MISC] + (wide ? 1 : 0);
+    NVK_HIP(hipMemsetAsync(counter, 0, sizeof(int), st));
+
+    AlignArgs g;
+    g.metas = metas;
+    g.rows = rows;
+    g.signal = a.signal;
+    g.spill_m = (double *)ctx->ws[wsm];
+    g.spill_e = (int32_t *)ctx->ws[wse];
+    g.bp = (uint32_t *)ctx->ws[wsb];
+    g.spill_stride = spill_stride;
+    g.bp_stride = bp_stride;
+    g.n_reads = (int)a.n_reads;
+    g.counter = counter;
+    g.H = H;
+    g.SR = SR;
+    g.transitions = transitions;
+    g.wide = wide;
+    g.c_cap = ALIGN1_C_CAP;
+    g.out_events = out_events;
+    g.out_status = out_status;
+
+    void (*kern)(AlignArgs) = nullptr;
+    switch (mel) {
+      case 0: kern = align_kernel<0>; break;
+      case 1: kern = align_kernel<1>; break;
+      case 2: kern = align_kernel<2>; break;
+      case 3: kern = align_kernel<3>; break;
+      default: kern = align_kernel<4>; break;
+    }
+    if (lds > 64 * 1024)
+      NVK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)slots), dim3(64), lds, st, g);
+    NVK_HIP(hipGetLastError());
   }
-  int max_steps = tot.max_steps < 1 ? 1 : tot.max_steps;
-  // waves resident per CU are bounded by LDS; more than 4 per SIMD buys nothing here
-  int per_cu = (int)((160 * 1024) / lds);
-  if (per_cu > 16) per_cu = 16;
-  if (per_cu < 1) per_cu = 1;
-  int64_t slots = ctx->slots_override > 0 ? ctx->slots_override : (int64_t)ctx->num_cus * per_cu;
-  if (slots > a.n_reads) slots = a.n_reads;
-  // per-slot workspace, padded by 2*PF steps so that prefetches past the end stay in bounds
-  const int64_t spill_stride = ((int64_t)max_steps + 2 * PF) * 64;
-  const int64_t bp_stride = (int64_t)((max_steps + 31) / 32 + 1) * 64;
-  const int64_t cap = (int64_t)64 << 30;
-  while (slots > 1 && slots * spill_stride * 12 > cap) slots /= 2;
-
-  int rc = nvk_ws_reserve(ctx, WS_SPILL, (size_t)slots * spill_stride * 8);
-  if (rc) return rc;
-  rc = nvk_ws_reserve(ctx, WS_STAGE, (size_t)slots * spill_stride * 4);
-  if (rc) return rc;
-  rc = nvk_ws_reserve(ctx, WS_BP, (size_t)slots * bp_stride * 4);
-  if (rc) return rc;
-  rc = nvk_ws_reserve(ctx, WS_MISC, 256);
-  if (rc) return rc;
-  int *counter = (int *)ctx->ws[WS_MISC];
-  NVK_HIP(hipMemsetAsync(counter, 0, sizeof(int), ctx->stream));
-
-  AlignArgs g;
-  g.metas = metas;
-  g.rows = rows;
-  g.signal = a.signal;
-  g.spill_m = (double *)ctx->ws[WS_SPILL];
-  g.spill_e = (int32_t *)ctx->ws[WS_STAGE];
-  g.bp = (uint32_t *)ctx->ws[WS_BP];
-  g.spill_stride = spill_stride;
-  g.bp_stride = bp_stride;
-  g.n_reads = (int)a.n_reads;
-  g.counter = counter;
-  g.H = H;
-  g.SR = SR;
-  g.transitions = transitions;
-  g.out_events = out_events;
-  g.out_status = out_status;
+  NVK_HIP(hipEventRecord(ctx->ev_join, ctx->stream2));
+  NVK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
   // bytes the sweeps stream through HBM: 12 B written + 12 B read per (step, lane) + path bits
   ctx->last_spill_bytes = (int64_t)tot.steps * 64 * 24 + (int64_t)tot.steps * 8 * 2;
-
-  void (*kern)(AlignArgs) = nullptr;
-  switch (mel) {
-    case 0: kern = align_kernel<0>; break;
-    case 1: kern = align_kernel<1>; break;
-    case 2: kern = align_kernel<2>; break;
-    case 3: kern = align_kernel<3>; break;
-    default: kern = align_kernel<4>; break;
-  }
-  if (lds > 64 * 1024)
-    NVK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  {
-    TimerScope ts(ctx, NVK_K_ALIGN);
-    hipLaunchKernelGGL(kern, dim3((unsigned)slots), dim3(64), lds, ctx->stream, g);
-  }
-  NVK_HIP(hipGetLastError());
   return NVK_OK;
 }

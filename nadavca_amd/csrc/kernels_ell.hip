@@ -240,7 +240,7 @@ __device__ void sweep(const FusedParam *desc, int R, int N, int c, const double 
 }
 
 template <int MEL>
-__global__ __launch_bounds__(64) void ell_kernel(EllArgs g) {
+__global__ __launch_bounds__(64, 3) void ell_kernel(EllArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double *ring = reinterpret_cast<double *>(smem);
   FusedParam *tab = reinterpret_cast<FusedParam *>(ring + g.SR);

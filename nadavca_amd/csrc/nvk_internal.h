@@ -35,6 +35,23 @@ struct __attribute__((aligned(16))) FusedParam {
 };
 static_assert(sizeof(FusedParam) == 80, "FusedParam layout");
 
+// refine_alignment v2: one entry per lane f = 0..R of a sweep (f = 0 is the all-ones start row,
+// f >= 1 is base f-1).  A lane owns up to two consecutive reference rows on ONE band:
+//   slot A  the emitting row (Gaussian of the base's k-mer, min event length mel), fed by the
+//           previous lane's last row through band [pbs, pbe];
+//   slot B  the transition row that follows it (constant density et, min event length 0,
+//           kmer_model.cpp:64-94), or the all-ones start row for f = 0.
+// Coordinates are those of the sweep (the suffix sweep runs on mirrored coordinates i' = N - i).
+struct __attribute__((aligned(16))) AlignLane {
+  double mean, ac, mc;  // slot A density
+  int32_t pbs, pbe;     // band of the predecessor row
+  int32_t bs, be;       // band of this lane's rows
+  int32_t flags;        // 1 has slot A, 2 has slot B, 4 slot B is the all-ones start row,
+                        // 8 slot B's transition is impossible (equal k-mer means -> density 0)
+  int32_t pad;          // lo: first cell the lane computes (band start minus warm-up / pre-roll)
+};
+static_assert(sizeof(AlignLane) == 48, "AlignLane layout");
+
 struct ReadMeta {
   int64_t sig_off;   // first sample of the read's signal slice
   int64_t row_off;   // first RowParam of the read
@@ -53,6 +70,7 @@ struct ReadMeta {
 // totals reduced over a batch by the planner (read back once by the host)
 struct PlanTotals {
   int32_t max_steps;
+  int32_t n_wide;   // reads whose skew exceeds the main launch's cap
   int32_t max_c;
   int32_t max_T;
   int32_t max_W;
@@ -70,11 +88,13 @@ struct DeviceModel {
 struct nvk_ctx {
   int device;
   hipStream_t stream;
+  hipStream_t stream2;   // side stream: the wide-skew class of the paired align kernel runs here
+  hipEvent_t ev_fork, ev_join;
   int slots_override;
   int num_cus;
   // growable workspaces (device)
-  void *ws[8];
-  size_t ws_bytes[8];
+  void *ws[12];
+  size_t ws_bytes[12];
   // timing
   int timing_on;
   double k_ms[NVK_K_COUNT];
@@ -90,7 +110,8 @@ struct nvk_model {
   double *d_mean, *d_ac, *d_mc;
 };
 
-enum { WS_META = 0, WS_ROWS = 1, WS_BANDTMP = 2, WS_SPILL = 3, WS_BP = 4, WS_MISC = 5, WS_ROWS2 = 6, WS_STAGE = 7 };
+enum { WS_META = 0, WS_ROWS = 1, WS_BANDTMP = 2, WS_SPILL = 3, WS_BP = 4, WS_MISC = 5, WS_ROWS2 = 6, WS_STAGE = 7,
+       WS_SPILL_B = 8, WS_STAGE_B = 9, WS_BP_B = 10, WS_COUNT = 11 };
 
 void nvk_set_error(const char *fmt, ...);
 int nvk_ws_reserve(nvk_ctx *ctx, int which, size_t bytes);
@@ -146,6 +167,18 @@ int launch_plan_ell(nvk_ctx *ctx, const DeviceModel &dm, const BatchArgs &a, int
                     const EllPlan &pl, unsigned long long *bandtmp, PlanTotals *totals);
 int launch_ell(nvk_ctx *ctx, const DeviceModel &dm, const BatchArgs &a, int wobbling,
                const EllPlan &pl, const PlanTotals &tot, double *out_ll, int32_t *out_status);
+struct Align2Plan {
+  ReadMeta *metas;
+  AlignLane *fwd;  // [total_ref + n] lanes of the prefix sweep
+  AlignLane *rev;  // [total_ref + n] lanes of the mirrored suffix sweep
+};
+constexpr int ALIGN1_C_CAP = 3;  // skew served by the main launch of the one-read-per-wave kernel
+constexpr int ALIGN2_C_CAP = 3;  // skew served by the main launch of the paired kernel
+int launch_plan_align2(nvk_ctx *ctx, const DeviceModel &dm, const BatchArgs &a, int transitions,
+                       int c_cap, const Align2Plan &pl, unsigned long long *bandtmp,
+                       PlanTotals *totals);
+int launch_align2(nvk_ctx *ctx, const BatchArgs &a, int transitions, const Align2Plan &pl,
+                  const PlanTotals &tot, int32_t *out_events, int32_t *out_status);
 int launch_expected(nvk_ctx *ctx, const DeviceModel &dm, int64_t n_reads, int64_t total_ref,
                     const int32_t *reference, const int64_t *ref_off, const int32_t *cb,
                     const int64_t *cb_off, const int32_t *ca, const int64_t *ca_off, double *out);

@@ -93,6 +93,10 @@ __device__ __forceinline__ bool gt_tol(X a, X b) {
   return diff > thr;
 }
 
+// c ? a : b.  (gfx950 note, tools/ubench_valu.hip: a v_cndmask_b32_e32 that re-reads an unchanged
+// vcc costs ~20 cycles, and hipcc lowers 64-bit selects to such pairs; forcing the e64/SGPR-mask
+// form through inline asm was measured and bought nothing at this kernel's occupancy, so the
+// plain form stays.)
 __device__ __forceinline__ X sel(bool c, X a, X b) { return X{c ? a.m : b.m, c ? a.e : b.e}; }
 
 // natural log of an extended number (used once per output value, never per cell)

@@ -122,3 +122,47 @@ def test_invalid_input_raises(dtw):
     m = dtw.KmerModel(*model)
     with pytest.raises(ValueError):
         dtw.refine_alignment(np.zeros(50), [0, 1, 2], [], [], [[5, 7]], 10, 2, m, True)  # anchor outside ref
+
+
+def test_paired_kernel_variant_matches(golden_config):
+    """The opt-in fused-lane / two-reads-per-wave kernel (NADAVCA_ALIGN_KERNEL=2) is a second
+    implementation of the same operator: run it in a child process (the variant is read from the
+    environment at call time) on the config-sized fixtures and on seeded reads."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r + "/tests")
+from conftest import GoldenFile
+from nadavca_amd import dtw, synthetic
+from oracle.oracle import Oracle
+g = GoldenFile("dp_config.npz")
+k, c, a, mean, sigma = g.model
+m = dtw.KmerModel(k, c, a, mean, sigma)
+reads = [(x["signal"], x["reference"], x["context_before"], x["context_after"], x["approximate_alignment"]) for x in g.cases]
+for tr in (0, 1):
+    got = dtw.refine_alignment_batch(reads, 150, 2, m, bool(tr))
+    for x, ev in zip(g.cases, got):
+        assert np.array_equal(ev, x["refine_t%%d" %% tr]), "golden mismatch"
+o = Oracle("port"); model = synthetic.synth_model_arrays(11, k=5, central=2)
+mg = dtw.KmerModel(*model); mo = o.KmerModel(*model)
+for mel in (0, 1, 2, 3, 4):
+    cases = []
+    for i in range(16):
+        rng = np.random.default_rng([77, mel, i]); R = int(rng.integers(3, 140))
+        cases.append(synthetic.make_dp_case(rng, model, R=R, bandwidth=int(rng.integers(8, 60)), dwell=(max(mel, 1), 9), jitter=6,
+                     anchor_density=float(rng.uniform(0.1, 0.9)), with_context=bool(i %% 3), trim=min(3, R // 3)))
+    rs = [(x["signal"], x["reference"], x["context_before"], x["context_after"], x["approximate_alignment"]) for x in cases]
+    for bw in (10, 45):
+        for tr in (False, True):
+            got = dtw.refine_alignment_batch(rs, bw, mel, mg, tr)
+            for x, ev in zip(cases, got):
+                exp = o.refine_alignment(x["signal"], x["reference"], x["context_before"], x["context_after"], x["approximate_alignment"], bw, mel, mo, tr)
+                assert ev.shape == exp.shape and np.array_equal(ev, exp), ("oracle mismatch", mel, bw, tr)
+print("PAIRED-OK")
+''' % (ROOT, ROOT)
+    env = dict(os.environ, NADAVCA_ALIGN_KERNEL='2')
+    p = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and 'PAIRED-OK' in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
