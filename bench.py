@@ -67,6 +67,21 @@ def cpu_baseline(batch, model, bandwidth, mel, workload, budget_reads_per_core=2
             'per_core': n / dt / cores}
 
 
+def measured_traffic(workload, n_reads):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/*_hbm_traffic.json; counters cannot be read from inside this process).  None when no
+    measurement exists for this workload/size."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_hbm_traffic.json')), reverse=True):
+        try:
+            t = json.load(open(path))
+        except Exception:
+            continue
+        if t.get('workload') == workload and int(t.get('reads_per_launch', -1)) == int(n_reads):
+            return t['bytes_per_launch']
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -166,7 +181,8 @@ def main():
             sec = ms / 1000.0 / launches
             ach = algo / sec / 1e9
             out['roofline'] = {'bound': 'hbm', 'kernel': kname, 'achieved': ach, 'peak': HBM_PEAK_GBS,
-                               'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS, 'traffic': None,
+                               'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
+                               'traffic': measured_traffic(args.workload, n_reads),
                                'algorithmic_bytes_per_launch': algo, 'kernel_ms_per_launch': ms / launches,
                                'all_kernels_ms': {k: v[0] / max(v[1], 1) for k, v in timing.items() if v[1]}}
         if not args.no_cpu_baseline:
