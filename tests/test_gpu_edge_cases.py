@@ -1,0 +1,102 @@
+"""GPU parity on the edges the reference's code paths have: tiny reads, duplicate / unsorted
+anchors ("later anchor overwrites", dtw.cpp:11-15), anchors on the last band row, empty batches,
+and a long read with a wide band (BASELINE config 5 shape)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dtw():
+    from nadavca_amd import dtw as d
+    return d
+
+
+def _both(dtw, oracle, model, case, bw, mel):
+    mg = dtw.KmerModel(*model)
+    mo = oracle.KmerModel(*model)
+    a = (case['signal'], case['reference'], case['context_before'], case['context_after'],
+         case['approximate_alignment'], bw, mel)
+    for flag in (True, False):
+        got = dtw.refine_alignment(*a, mg, flag)
+        exp = oracle.refine_alignment(*a, mo, flag)
+        assert got.shape == exp.shape and np.array_equal(got, exp), ('refine', flag)
+        ll = dtw.estimate_log_likelihoods(*a, mg, flag)
+        ex = oracle.estimate_log_likelihoods(*a, mo, flag)
+        assert np.array_equal(np.isneginf(ll), np.isneginf(ex)), ('ell -inf pattern', flag)
+        fin = np.isfinite(ex)
+        assert np.allclose(ll[fin], ex[fin], rtol=1e-9, atol=1e-9), ('ell', flag)
+
+
+def test_tiny_reads(dtw, oracle_port):
+    from nadavca_amd import synthetic
+    model = synthetic.synth_model_arrays(5, k=4, central=1)
+    for R in (1, 2, 3, 5):
+        for i in range(3):
+            rng = np.random.default_rng([901, R, i])
+            c = synthetic.make_dp_case(rng, model, R=R, bandwidth=12, dwell=(2, 6), jitter=2,
+                                       anchor_density=1.0, trim=0, pad_bases=3)
+            _both(dtw, oracle_port, model, c, 12, 2)
+
+
+def test_duplicate_unsorted_and_last_row_anchors(dtw, oracle_port):
+    from nadavca_amd import synthetic
+    model = synthetic.synth_model_arrays(6, k=4, central=1)
+    rng = np.random.default_rng(902)
+    c = synthetic.make_dp_case(rng, model, R=30, bandwidth=15, dwell=(3, 7), jitter=3)
+    anc = c['approximate_alignment'].copy()
+    # the same reference index twice (the later row must win), rows out of order, and an anchor
+    # on band row R (legal: the band arrays have R+1 entries)
+    dup = np.array([[int(anc[3][0]) + 4, int(anc[3][1])]], dtype=np.int32)
+    last = np.array([[len(c['signal']) - 2, 30]], dtype=np.int32)
+    mixed = np.concatenate([anc[:6], dup, anc[6:][::-1], last]).astype(np.int32)
+    c2 = dict(c, approximate_alignment=mixed)
+    _both(dtw, oracle_port, model, c2, 15, 2)
+
+
+def test_single_anchor_and_no_anchor(dtw, oracle_port):
+    from nadavca_amd import synthetic
+    model = synthetic.synth_model_arrays(7, k=4, central=1)
+    rng = np.random.default_rng(903)
+    c = synthetic.make_dp_case(rng, model, R=12, bandwidth=40, dwell=(3, 5), jitter=0)
+    one = dict(c, approximate_alignment=c['approximate_alignment'][:1])
+    _both(dtw, oracle_port, model, one, 40, 2)
+    none = dict(c, approximate_alignment=np.zeros((0, 2), dtype=np.int32))   # band = whole matrix
+    _both(dtw, oracle_port, model, none, 40, 2)
+
+
+def test_empty_batch_and_mixed_status(dtw, oracle_port):
+    from nadavca_amd import synthetic
+    model = synthetic.synth_model_arrays(8, k=4, central=1)
+    m = dtw.KmerModel(*model)
+    assert dtw.refine_alignment_batch([], 10, 2, m, True) == []
+    assert dtw.estimate_log_likelihoods_batch([], 10, 2, m, True) == []
+    rng = np.random.default_rng(904)
+    good = synthetic.make_dp_case(rng, model, R=20, bandwidth=15, dwell=(3, 6), jitter=2)
+    # no path: fewer samples than 2 * R
+    nopath = dict(signal=rng.normal(0, 1, 30), reference=rng.integers(0, 4, 20).astype(np.int32),
+                  context_before=np.zeros(0, np.int32), context_after=np.zeros(0, np.int32),
+                  approximate_alignment=np.array([[0, 0], [29, 19]], dtype=np.int32))
+    reads = [(c['signal'], c['reference'], c['context_before'], c['context_after'], c['approximate_alignment'])
+             for c in (good, nopath, good)]
+    out = dtw.refine_alignment_batch(reads, 15, 2, m, True)
+    assert len(out[0]) == 20 and len(out[1]) == 0 and np.array_equal(out[0], out[2])
+    ll = dtw.estimate_log_likelihoods_batch(reads, 15, 2, m, True)
+    assert np.all(np.isneginf(ll[1])) and np.all(np.isfinite(ll[0][np.arange(20), good['reference']]))
+
+
+def test_long_read_wide_band(dtw, oracle_port):
+    """BASELINE config 5 shape, scaled to what the CPU oracle finishes in seconds: ~1200 bases,
+    ~12000 samples, bandwidth 600 (skew c ~ 20, history and signal rings far larger than config 2)."""
+    from nadavca_amd import synthetic
+    model = synthetic.load_model_arrays()
+    mg = dtw.KmerModel(*model)
+    mo = oracle_port.KmerModel(*model)
+    rng = np.random.default_rng(905)
+    c = synthetic.make_dp_case(rng, model, R=1200, bandwidth=600, jitter=60, anchor_density=0.5)
+    a = (c['signal'], c['reference'], c['context_before'], c['context_after'], c['approximate_alignment'], 600, 2)
+    for tr in (True, False):
+        got = dtw.refine_alignment(*a, mg, tr)
+        exp = oracle_port.refine_alignment(*a, mo, tr)
+        assert np.array_equal(got, exp)
