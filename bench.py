@@ -185,7 +185,7 @@ def main():
                                'traffic': measured_traffic(args.workload, n_reads),
                                'algorithmic_bytes_per_launch': algo, 'kernel_ms_per_launch': ms / launches,
                                'all_kernels_ms': {k: v[0] / max(v[1], 1) for k, v in timing.items() if v[1]}}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported at N=1 only (contract)
             out['cpu_baseline'] = cpu_baseline(batch, model, bandwidth, mel, args.workload)
             out['gpu_over_cpu'] = out['value'] / world / out['cpu_baseline']['value']
         print(json.dumps(out), flush=True)

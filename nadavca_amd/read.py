@@ -65,25 +65,31 @@ class Read:
 
     @staticmethod
     def normalize_reads(reads):
-        """One median / median-absolute-deviation over ALL reads' samples, clip to +-5
-        (read.py:67-81).  numpy.median equals statistics.median on the same values."""
-        values = numpy.concatenate([numpy.asarray(r.raw_signal, dtype=float) for r in reads]) \
-            if reads else numpy.zeros(0)
-        shift = numpy.median(values)
-        scale = numpy.median(abs(values - shift))
-        for read in reads:
-            read.normalized_signal = numpy.clip((read.raw_signal - shift) / scale, -5, 5)
+        """Robust z-score with ONE centre and scale for the whole list: centre = median of every
+        raw sample of every read, scale = median absolute deviation from it; the result is clipped
+        to [-5, 5] and stored in ``normalized_signal`` (reference behaviour: read.py:67-81, where the
+        medians come from ``statistics.median`` — numerically the same as ``numpy.median``)."""
+        if not reads:
+            return
+        pooled = numpy.concatenate([numpy.asarray(r.raw_signal, dtype=float) for r in reads])
+        centre = numpy.median(pooled)
+        spread = numpy.median(abs(pooled - centre))
+        for r in reads:
+            r.normalized_signal = numpy.clip((r.raw_signal - centre) / spread, -5, 5)
 
     def tweak_signal_normalization(self, alignment, expected_means):
-        """Smoothing spline from event means to expected levels, applied to the whole signal
-        (read.py:83-94).  alignment: (R, 2) absolute event ranges."""
-        data = []
-        for event, expected_mean in zip(alignment, expected_means):
-            mean = numpy.mean(self.normalized_signal[event[0]: event[1]])
-            if abs(expected_mean - mean) <= 1:
-                data.append((mean, expected_mean))
-        data.sort()
-        means = [d[0] for d in data]
-        expected = [d[1] for d in data]
-        spline = interpolate.splrep(means, expected, s=len(means))
-        self.tweaked_normalized_signal = interpolate.splev(self.normalized_signal, spline)
+        """Re-normalise the read against the pore model (reference behaviour: read.py:83-94).
+        For every aligned event (absolute sample range per row of ``alignment``) take the mean of
+        ``normalized_signal``; keep the events whose mean is within 1 of the model's expected level;
+        fit a smoothing spline (FITPACK ``splrep`` with s = number of points) from observed mean to
+        expected level and apply it to the whole signal -> ``tweaked_normalized_signal``."""
+        signal = self.normalized_signal
+        pairs = []
+        for (first, last), level in zip((tuple(ev[:2]) for ev in alignment), expected_means):
+            observed = numpy.mean(signal[first:last])
+            if abs(level - observed) <= 1:
+                pairs.append((observed, level))
+        pairs.sort()
+        xs, ys = [p[0] for p in pairs], [p[1] for p in pairs]
+        knots = interpolate.splrep(xs, ys, s=len(xs))
+        self.tweaked_normalized_signal = interpolate.splev(signal, knots)
