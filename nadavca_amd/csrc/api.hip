@@ -462,9 +462,11 @@ extern "C" int nvk_refine_alignment_batch_dev(
   a.bandwidth = bandwidth;
   a.mel = min_event_length;
   PlanTotals tot;
-  // two implementations of the same operator with identical results: the one-row-per-lane,
-  // one-read-per-wave kernel (kernels_align.hip) is the default; the fused-lane, two-reads-per-wave
-  // kernel (kernels_align2.hip) is selected with NADAVCA_ALIGN_KERNEL=2 (both are parity-tested)
+  // three implementations of the same operator with identical results (all parity-tested):
+  //   default                  kernels_align3.hip (plain doubles, wave-uniform scale) with
+  //                            kernels_align.hip as the exact fallback for reads it flags
+  //   NADAVCA_ALIGN_KERNEL=1   kernels_align.hip only (mantissa+exponent per value)
+  //   NADAVCA_ALIGN_KERNEL=2   kernels_align2.hip (fused lanes, two reads per wave)
   const char *force = getenv("NADAVCA_ALIGN_KERNEL");
   bool use_v1 = !(force && force[0] == '2');
   if (!use_v1) {
@@ -493,9 +495,27 @@ extern "C" int nvk_refine_alignment_batch_dev(
   if (use_v1) {
     rc = plan_batch(model, a, model_transitions ? PLAN_ALIGN_TRANS : PLAN_ALIGN_PLAIN, 0, tot);
     if (rc) return rc;
-    rc = launch_align(ctx, a, model_transitions ? 1 : 0, (const ReadMeta *)ctx->ws[WS_META],
-                      (const RowParam *)ctx->ws[WS_ROWS], tot, out_events, out_status);
-    if (rc) return rc;
+    const ReadMeta *metas = (const ReadMeta *)ctx->ws[WS_META];
+    const RowParam *rows = (const RowParam *)ctx->ws[WS_ROWS];
+    bool exact_all = force && force[0] == '1';
+    if (!exact_all) {
+      // fast path: plain doubles under a wave-uniform scale (bit-identical while in range);
+      // reads it cannot serve come back flagged and are redone by the exact kernel below
+      int n_retry = 0;
+      rc = launch_align3(ctx, a, model_transitions ? 1 : 0, metas, rows, tot, out_events, out_status,
+                         &n_retry);
+      if (rc == NVK_ERR_UNSUPPORTED) exact_all = true;
+      else if (rc) return rc;
+      else if (n_retry > 0 && !getenv("NADAVCA_ALIGN3_NORETRY")) {  // (debug switch: leave flags visible)
+        rc = launch_align_retry(ctx, a, model_transitions ? 1 : 0, metas, rows, tot, out_events,
+                                out_status);
+        if (rc) return rc;
+      }
+    }
+    if (exact_all) {
+      rc = launch_align(ctx, a, model_transitions ? 1 : 0, metas, rows, tot, out_events, out_status);
+      if (rc) return rc;
+    }
   }
   NVK_HIP(hipStreamSynchronize(ctx->stream));
   return NVK_OK;

@@ -59,6 +59,7 @@ struct AlignArgs {
   int SR;  // signal ring samples (pow2 >= 64*c + CH)
   int transitions;
   int wide, c_cap;  // class served by this launch: skew <= c_cap (wide = 0) or above (wide = 1)
+  int only_retry;   // serve only reads flagged NVK_READ_RETRY_INTERNAL by the scaled-double kernel
   int32_t *out_events;
   int32_t *out_status;
 };
@@ -118,6 +119,7 @@ __global__ __launch_bounds__(64) void align_kernel(AlignArgs g) {
       continue;
     }
     if ((m.c > g.c_cap) != (g.wide != 0)) continue;  // served by the other launch
+    if (g.only_retry && g.out_status[rd] != NVK_READ_RETRY_INTERNAL) continue;
     const int T = __builtin_amdgcn_readfirstlane(m.T);
     const int N = __builtin_amdgcn_readfirstlane(m.N);
     const int c = __builtin_amdgcn_readfirstlane(m.c);
@@ -434,9 +436,25 @@ __global__ __launch_bounds__(64) void align_kernel(AlignArgs g) {
 
 }  // namespace
 
+static int launch_align_impl(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadMeta *metas,
+                             const RowParam *rows, const PlanTotals &tot, int32_t *out_events,
+                             int32_t *out_status, int only_retry);
+
 int launch_align(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadMeta *metas,
                  const RowParam *rows, const PlanTotals &tot, int32_t *out_events,
                  int32_t *out_status) {
+  return launch_align_impl(ctx, a, transitions, metas, rows, tot, out_events, out_status, 0);
+}
+
+int launch_align_retry(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadMeta *metas,
+                       const RowParam *rows, const PlanTotals &tot, int32_t *out_events,
+                       int32_t *out_status) {
+  return launch_align_impl(ctx, a, transitions, metas, rows, tot, out_events, out_status, 1);
+}
+
+static int launch_align_impl(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadMeta *metas,
+                             const RowParam *rows, const PlanTotals &tot, int32_t *out_events,
+                             int32_t *out_status, int only_retry) {
   if (a.n_reads == 0) return NVK_OK;
   const int mel = a.mel;
   if (mel < 0 || mel > 4) {
@@ -503,6 +521,7 @@ int launch_align(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadMe
     g.transitions = transitions;
     g.wide = wide;
     g.c_cap = ALIGN1_C_CAP;
+    g.only_retry = only_retry;
     g.out_events = out_events;
     g.out_status = out_status;
 

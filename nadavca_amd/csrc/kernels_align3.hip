@@ -1,0 +1,622 @@
+// refine_alignment v3 on gfx950: plain doubles under a wave-uniform running scale.
+//
+// Same mathematics, mapping and memory layout as kernels_align.hip (one row per lane, one read per
+// wave, systolic anti-diagonal wavefront, suffix spill in (step, lane) order, one update bit per
+// cell instead of a back-pointer) — read that file's header first.  What changes is the number
+// representation, which is where most of that kernel's instructions went:
+//
+//   kernels_align.hip keeps every probability as (double mantissa, int32 exponent) and pays
+//   ldexp/frexp/max/select chains and a third register per value for it.  But all values a wave
+//   touches in one step lie on one anti-diagonal of the band, i.e. within a few hundred bits of
+//   each other.  So here a value is a PLAIN double, stored as  true * 2^L(u)  with ONE running
+//   log-scale L per wave and step, kept in scalar registers.  Every RS steps the wave looks at its
+//   largest live exponent and moves L so that it sits at 2^TARGET; the move is applied by adding
+//   the shift to the exponent of that step's densities (an integer add on a value that is being
+//   ldexp'ed anyway), and a neighbour value from D steps ago is brought to the current scale by
+//   the (scalar) sum of the shifts of those D steps — zero on most steps, so the ldexp is skipped.
+//   Scaling by powers of two is exact, so as long as nothing leaves the double range the results
+//   are BIT-IDENTICAL to the exact kernel; any under/overflow is detected per read and that read
+//   is re-run by the exact kernel (status NVK_READ_RETRY_INTERNAL, never visible to callers).
+//
+//   Path DP: scores of one row only ever meet scores of the same row (running maximum, arg-max)
+//   or are handed to the next row, so each row carries its own scale: the receiving lane
+//   normalises the running maximum once per row (rho) and passes the accumulated exponent G along
+//   with the score, which is all the tie tolerance of xm::gt_tol needs.
+//
+// Spill: 8 B per cell (+4 B per step for L) instead of 12 B per cell.
+#include <math.h>
+
+#include "nvk_internal.h"
+#include "xmath.h"
+
+namespace {
+
+constexpr int CH = 128;     // signal refill chunk (samples)
+constexpr int TABN = 128;   // row-table window (two 64-row blocks)
+constexpr int PF = 4;       // forward sweep: spill prefetch depth (steps)
+constexpr int RS = 16;      // rescale period (steps); must exceed c + mel
+constexpr int TARGET = 250; // exponent the largest live value is moved to
+#define HUGE_V 0x1.0p+900
+#define MASS_TOL 1e-9          // allowed relative spread of the rows' posterior mass
+
+#define WAVE_SYNC()                                        \
+  do {                                                     \
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); \
+    __builtin_amdgcn_wave_barrier();                       \
+  } while (0)
+
+struct Align3Args {
+  const ReadMeta *metas;
+  const RowParam *rows;
+  const double *signal;
+  double *spill_v;   // suffix values, [slot][step][lane], scaled by 2^L(step)
+  int32_t *spill_L;  // [slot][step] running log-scale of the reverse sweep
+  uint32_t *bp;      // path update bits, [slot][step/32][lane]
+  int64_t spill_stride;  // cells per slot
+  int64_t L_stride;      // ints per slot
+  int64_t bp_stride;     // words per slot
+  int n_reads;
+  int *counter;
+  int H, SR;
+  int transitions;
+  int c_cap;
+  int *n_retry;      // reads handed to the exact kernel
+  int32_t *out_events;
+  int32_t *out_status;
+};
+
+__device__ __forceinline__ void load_tab_block(RowParam *tab, const RowParam *rows, int blk, int T,
+                                               int lane) {
+  int r = blk * 64 + lane;
+  if (r >= 0 && r < T) tab[r & (TABN - 1)] = rows[r];
+}
+
+// e(x) * 2^dshift as a plain double; constant rows have mc2 == 0, impossible ones ac2 == -inf.
+// ac2/mc2: the reference's constants (kmer_model.cpp:9-12,48-50) times log2(e).
+__device__ __forceinline__ double density(double x, double mean, double ac2, double mc2, int dshift) {
+  double d = x - mean;
+  double y = fmax(ac2 - d * d * mc2, xm::YCLAMP);
+  double k = rint(y);
+  double p = xm::exp2_frac(y - k);
+  double e = ldexp(p, (int)k + dshift);
+  return (y <= xm::YCLAMP * 0.5) ? 0.0 : e;
+}
+
+template <int MEL>
+__device__ __forceinline__ double emission_product(double e, double e1, double e2, double e3) {
+  double P = 1.0;  // newest first, as the reference multiplies (node_next_row.h:27-29,51-53)
+  if (MEL >= 1) P = e;
+  if (MEL >= 2) P = P * e1;
+  if (MEL >= 3) P = P * e2;
+  if (MEL >= 4) P = P * e3;
+  return P;
+}
+
+__device__ __forceinline__ int wave_max_i(int v) {
+  for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d, 64));
+  return v;
+}
+
+// running scale: L(u) = L(u-1) + delta_u; delta is nonzero only on rescale steps
+struct Scale {
+  int L;        // current log-scale
+  int u_last;   // step of the last rescale
+  int d_last;   // its shift
+  int d_next;   // shift of the NEXT step (densities are computed one step ahead)
+};
+
+template <int MEL>
+__global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double *ring = reinterpret_cast<double *>(smem);
+  RowParam *tab = reinterpret_cast<RowParam *>(ring + g.SR);
+  double *hist = reinterpret_cast<double *>(tab + TABN);
+  double *dhist = hist + (size_t)g.H * 64;
+  int *ghist = reinterpret_cast<int *>(dhist + (size_t)g.H * 64);
+  int *s_read = ghist + (size_t)g.H * 64;
+
+  const int lane = threadIdx.x;
+  const int H = g.H, RM = g.SR - 1;
+  double *spill_v = g.spill_v + (size_t)blockIdx.x * g.spill_stride;
+  int32_t *spill_L = g.spill_L + (size_t)blockIdx.x * g.L_stride;
+  uint32_t *bp = g.bp + (size_t)blockIdx.x * g.bp_stride;
+
+  for (int q = lane; q < g.SR; q += 64) ring[q] = 0.0;
+
+  while (true) {
+    __syncthreads();
+    if (lane == 0) *s_read = atomicAdd(g.counter, 1);
+    __syncthreads();
+    const int rd = __builtin_amdgcn_readfirstlane(*s_read);
+    if (rd >= g.n_reads) break;
+    const ReadMeta m = g.metas[rd];
+    if (m.status != NVK_READ_OK) {
+      if (lane == 0) g.out_status[rd] = m.status;
+      continue;
+    }
+    if (m.c > g.c_cap) {  // band too wide for this launch's LDS rings: exact kernel
+      if (lane == 0) {
+        g.out_status[rd] = NVK_READ_RETRY_INTERNAL;
+        atomicAdd(g.n_retry, 1);
+      }
+      continue;
+    }
+    const int T = __builtin_amdgcn_readfirstlane(m.T);
+    const int N = __builtin_amdgcn_readfirstlane(m.N);
+    const int c = __builtin_amdgcn_readfirstlane(m.c);
+    const int t_min = __builtin_amdgcn_readfirstlane(m.t_min);
+    const int n_steps = __builtin_amdgcn_readfirstlane(m.n_steps);
+    const int t_max = t_min + n_steps - 1;
+    const RowParam *rows = g.rows + m.row_off;
+    const double *sig = g.signal + m.sig_off;
+    const int top = T - 1;
+    int K = 0;          // true exponent of the largest suffix[0][.]
+    bool suspect = false;  // something left the double range: the exact kernel must redo this read
+    const int sA0 = ((-c - MEL) % H + H) % H, sB0 = ((-c) % H + H) % H;
+
+    // =========================== reverse sweep: suffix rows -> spill ===========================
+    {
+      int r = top - ((top - lane) & 63);
+      int loaded_lo = top >> 6;
+      load_tab_block(tab, rows, loaded_lo, T, lane);
+      if (loaded_lo > 0) {
+        loaded_lo--;
+        load_tab_block(tab, rows, loaded_lo, T, lane);
+      }
+      __syncthreads();
+      double mean = 0, ac2 = 0, mc2 = 0;
+      int bs = 0x40000000, hi = -0x40000000, pbs = 0, pbe = -1, melr = 0;
+      bool is_init = false;
+      if (r >= 0) {
+        const RowParam &o = tab[r & (TABN - 1)];
+        mean = o.mean; ac2 = o.ac * xm::LOG2E; mc2 = o.mc * xm::LOG2E; melr = o.mel;
+        bs = o.bs; hi = o.hi;
+        is_init = (r == top);
+        if (!is_init) {
+          const RowParam &p = tab[(r + 1) & (TABN - 1)];
+          pbs = p.bs; pbe = p.be;
+        }
+      }
+      int i = t_max - c * r;
+      double prev = 0.0, e1 = 1.0, e2 = 1.0, e3 = 1.0;
+      int kmax = -0x40000000;
+      int r_old = top;
+      int filled_lo = ((t_max - c * top) / CH + 1) * CH;
+      while (t_max - c * r_old < filled_lo) {
+        filled_lo -= CH;
+        for (int q = lane; q < CH; q += 64) {
+          int idx = filled_lo + q;
+          ring[idx & RM] = (idx >= 0 && idx < N) ? sig[idx] : 0.0;
+        }
+      }
+      __syncthreads();
+      Scale sc{0, -0x40000000, 0, 0};
+      double e = density(ring[i & RM], mean, ac2, mc2, 0);
+      int su = 0, sA = sA0, sB = sB0;
+
+      for (int u = 0; u < n_steps; ++u) {
+        const int t = t_max - u;
+        // this step's shift was decided at the end of the previous one
+        if (sc.d_next != 0) {
+          sc.L += sc.d_next;
+          sc.u_last = u;
+          sc.d_last = sc.d_next;
+          sc.d_next = 0;
+        }
+        bool fin = (r >= 0) && (i < bs);
+        if (__any(fin)) {
+          int nr = r - 64;
+          if (__any(fin && nr >= 0 && (nr >> 6) < loaded_lo)) {
+            loaded_lo--;
+            load_tab_block(tab, rows, loaded_lo, T, lane);
+            __syncthreads();
+          }
+          if (fin) {
+            r = nr;
+            i += 64 * c;
+            prev = 0.0;
+            if (r >= 0) {
+              const RowParam &o = tab[r & (TABN - 1)];
+              const RowParam &p = tab[(r + 1) & (TABN - 1)];
+              mean = o.mean; ac2 = o.ac * xm::LOG2E; mc2 = o.mc * xm::LOG2E; melr = o.mel;
+              bs = o.bs; hi = o.hi; pbs = p.bs; pbe = p.be;
+              is_init = false;
+              e = density(ring[i & RM], mean, ac2, mc2, (sc.u_last == u) ? sc.d_last : 0);
+            } else {
+              hi = -0x40000000; bs = 0x40000000;
+            }
+          }
+          while (r_old >= 0 && __shfl(r, r_old & 63, 64) != r_old) r_old--;
+        }
+        if (r_old >= 0) {
+          int need_min = t - 1 - c * r_old;
+          while (need_min < filled_lo) {
+            filled_lo -= CH;
+            __syncthreads();
+            for (int q = lane; q < CH; q += 64) {
+              int idx = filled_lo + q;
+              ring[idx & RM] = (idx >= 0 && idx < N) ? sig[idx] : 0.0;
+            }
+            __syncthreads();
+          }
+        }
+        // scalar shifts that bring a neighbour value from D steps ago to the current scale
+        const int age = u - sc.u_last;
+        const int shT = (age < c) ? sc.d_last : 0;                       // D = c      (mel 0 rows)
+        const int shE = (age >= MEL && age < c + MEL) ? sc.d_last : 0;  // D = c+MEL  (beyond the densities' own shifts)
+        // ---- the cell (r, i): out = P * pred[i + mel] + e(s[i]) * out[i + 1]
+        const bool active = (r >= 0) && (i <= hi) && (i >= bs);
+        double P = emission_product<MEL>(e, e1, e2, e3);
+        P = (melr == 0) ? 1.0 : P;
+        const int j = i + melr;
+        const int hs = (melr == 0 ? sB : sA) * 64 + ((lane + 1) & 63);
+        double pv = hist[hs];
+        pv = (j >= pbs && j <= pbe) ? pv : 0.0;
+        double t1 = P * pv;
+        if ((shT | shE) != 0) t1 = ldexp(t1, melr == 0 ? shT : shE);
+        const double t2 = e * prev;
+        double o = t1 + t2;
+        const bool valid = active && (j <= N);
+        o = valid ? o : 0.0;
+        if (is_init) o = active ? ldexp(1.0, sc.L) : 0.0;
+        // Cells far off the likely path are thousands of bits below the wave's largest value and
+        // flush to zero here; that cannot change any value that matters (their contributions are
+        // below 2^-53 of it in exact arithmetic too).  Overflow / NaN must never happen.
+        suspect |= !(o <= HUGE_V);
+        prev = o;
+        if (r == 0 && o != 0.0) kmax = max(kmax, __builtin_amdgcn_frexp_exp(o) - sc.L);
+        hist[su * 64 + lane] = o;
+        spill_v[(size_t)(t - t_min) * 64 + lane] = o;
+        if (lane == 0) spill_L[t - t_min] = sc.L;
+        // ---- rescale decision for the next step, then the next step's density
+        if (((u + 1) % RS) == 0) {
+          int ex = (o != 0.0) ? __builtin_amdgcn_frexp_exp(o) : -0x40000000;
+          int mx = wave_max_i(ex);
+          sc.d_next = (mx > -0x40000000) ? (TARGET - mx) : 0;
+        }
+        i -= 1;
+        e3 = e2; e2 = e1; e1 = e;
+        e = density(ring[i & RM], mean, ac2, mc2, sc.d_next);
+        su = (su + 1 == H) ? 0 : su + 1;
+        sA = (sA + 1 == H) ? 0 : sA + 1;
+        sB = (sB + 1 == H) ? 0 : sB + 1;
+        WAVE_SYNC();
+      }
+      K = __shfl(kmax, 0, 64);
+      if (K == -0x40000000) K = 0;
+    }
+    __syncthreads();
+
+    // ================= forward sweep: prefix rows, posterior, path DP, update bits =================
+    double fbest = 0.0, fthr = 0.0;
+    int fidx = -1, fG = 0;
+    {
+      int r = lane;
+      int loaded_hi = 0;
+      load_tab_block(tab, rows, 0, T, lane);
+      __syncthreads();
+      double mean = 0, ac2 = 0, mc2 = 0;
+      int bs = 0, be = -0x40000000, lo = 0x40000000, pbs = 0, pbe = -1, melr = 0;
+      bool is_init = false;
+      if (r < T) {
+        const RowParam &o = tab[r & (TABN - 1)];
+        bs = o.bs; be = o.be; lo = o.lo;
+        is_init = (r == 0);
+        if (!is_init) {
+          const RowParam &p = tab[(r - 1) & (TABN - 1)];
+          mean = p.mean; ac2 = p.ac * xm::LOG2E; mc2 = p.mc * xm::LOG2E; melr = p.mel;
+          pbs = p.bs; pbe = p.be;
+        }
+      }
+      int i = t_min - c * r;
+      double prev = 0.0, e1 = 1.0, e2 = 1.0, e3 = 1.0;
+      // path DP state of the row: running maximum of the previous row's scores (raw, as received,
+      // and normalised by 2^rho), its tolerance margin, the row's accumulated exponent G
+      double best = 0.0, bestn = 0.0, bthr = 0.0;
+      int Gb = 0, G = 0;  // scale of `best` as received; scale of this row's scores
+      // Flush detector.  In a banded forward-backward pass every allowed path crosses every row
+      // exactly once, so sum_i prefix[r][i] * suffix[r][i] is the SAME total for every row r.
+      // Cells far below the wave's scale flush to zero here; if that ever removes mass that
+      // matters, some row's sum deviates — checked over all rows at the end of the read.
+      double rsum = 0.0, smin = INFINITY, smax = 0.0;
+      uint32_t bits = 0;
+      int r_old = 0;
+      int filled_hi = ((t_min - MEL - 1) > 0 ? (t_min - MEL - 1) / CH : 0) * CH;
+      while (t_min - 1 >= filled_hi) {
+        for (int w = lane; w < CH; w += 64) {
+          int idx = filled_hi + w;
+          ring[idx & RM] = (idx >= 0 && idx < N) ? sig[idx] : 0.0;
+        }
+        filled_hi += CH;
+      }
+      __syncthreads();
+      Scale sc{0, -0x40000000, 0, 0};
+      double e = density(ring[(i - 1) & RM], mean, ac2, mc2, 0);
+      int su = 0, sA = sA0, sB = sB0;
+
+      double cur_v[PF];
+      int cur_L[PF];
+#pragma unroll
+      for (int q = 0; q < PF; q++) {
+        cur_v[q] = spill_v[(size_t)q * 64 + lane];
+        cur_L[q] = spill_L[q];
+      }
+
+      for (int ub = 0; ub < n_steps; ub += PF) {
+#pragma unroll
+        for (int q = 0; q < PF; q++) {
+          const int u = ub + q;
+          if (u < n_steps) {
+            const int t = t_min + u;
+            if (sc.d_next != 0) {
+              sc.L += sc.d_next;
+              sc.u_last = u;
+              sc.d_last = sc.d_next;
+              sc.d_next = 0;
+            }
+            bool fin = (r < T) && (i > be);
+            if (__any(fin)) {
+              int nr = r + 64;
+              if (__any(fin && nr < T && (nr >> 6) > loaded_hi)) {
+                loaded_hi++;
+                load_tab_block(tab, rows, loaded_hi, T, lane);
+                __syncthreads();
+              }
+              if (fin) {
+                smin = fmin(smin, rsum);
+                smax = fmax(smax, rsum);
+                rsum = 0.0;
+                r = nr;
+                i -= 64 * c;
+                prev = 0.0;
+                best = 0.0; bestn = 0.0; bthr = 0.0; Gb = 0; G = 0;
+                if (r < T) {
+                  const RowParam &o = tab[r & (TABN - 1)];
+                  const RowParam &p = tab[(r - 1) & (TABN - 1)];
+                  bs = o.bs; be = o.be; lo = o.lo;
+                  mean = p.mean; ac2 = p.ac * xm::LOG2E; mc2 = p.mc * xm::LOG2E; melr = p.mel;
+                  pbs = p.bs; pbe = p.be;
+                  is_init = false;
+                  e = density(ring[(i - 1) & RM], mean, ac2, mc2, (sc.u_last == u) ? sc.d_last : 0);
+                } else {
+                  lo = 0x40000000; be = -0x40000000;
+                }
+              }
+              while (r_old < T && __shfl(r, r_old & 63, 64) != r_old) r_old++;
+            }
+            if (r_old < T) {
+              int need_max = t + 1 - c * r_old - 1;
+              while (need_max >= filled_hi) {
+                __syncthreads();
+                for (int w = lane; w < CH; w += 64) {
+                  int idx = filled_hi + w;
+                  ring[idx & RM] = (idx >= 0 && idx < N) ? sig[idx] : 0.0;
+                }
+                filled_hi += CH;
+                __syncthreads();
+              }
+            }
+            const int age = u - sc.u_last;
+            const int shT = (age < c) ? sc.d_last : 0;
+            const int shE = (age >= MEL && age < c + MEL) ? sc.d_last : 0;
+            // ---- the cell (r, i): out = P * pred[i - mel] + e(s[i-1]) * out[i - 1]
+            const bool active = (r < T) && (i >= lo) && (i <= be);
+            const bool in_band = active && (i >= bs);
+            double P = emission_product<MEL>(e, e1, e2, e3);
+            P = (melr == 0) ? 1.0 : P;
+            const int j = i - melr;
+            const bool ok = (j >= pbs) && (j <= pbe);
+            const int hs = (melr == 0 ? sB : sA) * 64 + ((lane - 1) & 63);
+            double pv = hist[hs];
+            double dv = dhist[hs];
+            const int Gin = ghist[hs];
+            pv = ok ? pv : 0.0;
+            dv = ok ? dv : 0.0;
+            double t1 = P * pv;
+            if ((shT | shE) != 0) t1 = ldexp(t1, melr == 0 ? shT : shE);
+            const double t2 = e * prev;
+            double o = t1 + t2;
+            const bool valid = active && (i >= melr);
+            o = valid ? o : 0.0;
+            if (is_init) o = in_band ? ldexp(1.0, sc.L) : 0.0;
+            suspect |= !(o <= HUGE_V);
+            prev = o;
+            // ---- posterior of the cell, on the scale 2^-K:  post = prefix * suffix
+            const double suf = cur_v[q];
+            const int kap = -(sc.L + cur_L[q]) - K;
+            const double post = in_band ? ldexp(o * suf, kap) : 0.0;
+            rsum += post;
+            // ---- path step (node.cpp:52-91): running maximum of the previous row, strict '>' at the
+            // resolution of the reference's log-doubles (xm::gt_tol): margin = best * |exponent| * 2^-52
+            // Scores are (double, integer scale): stored = true * 2^scale.  The running maximum keeps
+            // the scale it arrived with; an incoming score is brought onto it before comparing
+            // (far below -> 0, far above -> inf, both compare correctly).
+            const double dva = ldexp(dv, (best == 0.0) ? 0 : Gb - Gin);
+            const bool upd = active && (dva - best > bthr);
+            if (upd) {
+              const int ex = __builtin_amdgcn_frexp_exp(dv);
+              best = dv;
+              Gb = Gin;
+              bestn = __builtin_amdgcn_frexp_mant(dv);  // dv * 2^-ex
+              G = Gin - ex;                             // scale of bestn * post
+              bthr = dv * ((double)abs(ex - Gin) * 0x1.0p-52);
+            }
+            bits |= upd ? (1u << (u & 31)) : 0u;
+            double dpv = is_init ? post : bestn * post;
+            dpv = in_band ? dpv : 0.0;
+            const int Gd = is_init ? 0 : G;
+            if (__any(r == top && in_band)) {
+              const double da = ldexp(dpv, (fbest == 0.0) ? 0 : fG - Gd);
+              if (r == top && (da - fbest > fthr)) {
+                fbest = dpv;
+                fG = Gd;
+                fidx = i;
+                fthr = dpv * ((double)abs(__builtin_amdgcn_frexp_exp(dpv) - Gd) * 0x1.0p-52);
+              }
+            }
+            hist[su * 64 + lane] = o;
+            dhist[su * 64 + lane] = dpv;
+            ghist[su * 64 + lane] = Gd;
+            if ((u & 31) == 31 || u == n_steps - 1) {
+              bp[(size_t)(u >> 5) * 64 + lane] = bits;
+              bits = 0;
+            }
+            // refill the prefetch slot just consumed
+            cur_v[q] = spill_v[(size_t)(u + PF) * 64 + lane];
+            cur_L[q] = spill_L[u + PF];
+            // ---- rescale decision for the next step, then the next step's density
+            if (((u + 1) % RS) == 0) {
+              int ex = (o != 0.0) ? __builtin_amdgcn_frexp_exp(o) : -0x40000000;
+              int mx = wave_max_i(ex);
+              sc.d_next = (mx > -0x40000000) ? (TARGET - mx) : 0;
+            }
+            i += 1;
+            e3 = e2; e2 = e1; e1 = e;
+            e = density(ring[(i - 1) & RM], mean, ac2, mc2, sc.d_next);
+            su = (su + 1 == H) ? 0 : su + 1;
+            sA = (sA + 1 == H) ? 0 : sA + 1;
+            sB = (sB + 1 == H) ? 0 : sB + 1;
+            WAVE_SYNC();
+          }
+        }
+      }
+      if (r < T) {  // rows still open when the sweep ends
+        smin = fmin(smin, rsum);
+        smax = fmax(smax, rsum);
+      }
+      for (int dlt = 32; dlt >= 1; dlt >>= 1) {
+        smin = fmin(smin, __shfl_xor(smin, dlt, 64));
+        smax = fmax(smax, __shfl_xor(smax, dlt, 64));
+      }
+      suspect |= !(smin > 0.0 && smax <= smin * (1.0 + MASS_TOL));
+    }
+    __syncthreads();
+
+    // ====================================== traceback ============================================
+    int idx = __shfl(fidx, top & 63, 64);
+    const bool any_suspect = __any(suspect);
+    if (any_suspect || (idx < 0 && K != 0)) {
+      // out of range somewhere, or no path although the suffix sweep found mass: exact kernel
+      if (lane == 0) {
+        g.out_status[rd] = NVK_READ_RETRY_INTERNAL;
+        atomicAdd(g.n_retry, 1);
+      }
+      continue;
+    }
+    if (idx < 0) {
+      if (lane == 0) g.out_status[rd] = NVK_READ_NO_PATH;
+      continue;
+    }
+    if (lane == 0) {
+      int32_t *ev = g.out_events + 2 * m.ref_off;
+      int st = NVK_READ_OK;
+      for (int r = top; r >= 0; --r) {
+        if (g.transitions) {
+          ev[2 * (r >> 1) + (r & 1)] = idx;
+        } else {
+          if (r > 0) ev[2 * (r - 1) + 1] = idx;
+          if (r < top) ev[2 * r] = idx;
+        }
+        if (r == 0) break;
+        const int pm = g.transitions ? ((r - 1) & 1 ? 0 : MEL) : MEL;
+        int u = idx + c * r - t_min;
+        int w = u >> 5;
+        uint32_t v = bp[(size_t)w * 64 + (r & 63)] & (0xffffffffu >> (31 - (u & 31)));
+        while (v == 0 && w > 0) {
+          --w;
+          v = bp[(size_t)w * 64 + (r & 63)];
+        }
+        if (v == 0) {
+          st = NVK_READ_RETRY_INTERNAL;
+          atomicAdd(g.n_retry, 1);
+          break;
+        }
+        int uu = (w << 5) + (31 - __clz(v));
+        idx = uu + t_min - c * r - pm;
+      }
+      g.out_status[rd] = st;
+    }
+  }
+}
+
+}  // namespace
+
+int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadMeta *metas,
+                  const RowParam *rows, const PlanTotals &tot, int32_t *out_events,
+                  int32_t *out_status, int *n_retry) {
+  *n_retry = 0;
+  if (a.n_reads == 0) return NVK_OK;
+  const int mel = a.mel;
+  if (mel < 0 || mel > 4) {
+    nvk_set_error("min_event_length %d outside the compiled range 0..4", mel);
+    return NVK_ERR_UNSUPPORTED;
+  }
+  const int max_c = tot.max_c < 1 ? 1 : tot.max_c;
+  const int max_steps = tot.max_steps < 1 ? 1 : tot.max_steps;
+  const int c = max_c < ALIGN1_C_CAP ? max_c : ALIGN1_C_CAP;  // wider reads go to the exact kernel
+  if (c + mel + 1 >= RS) return NVK_ERR_UNSUPPORTED;
+  const int H = c + mel + 1;
+  int SR = 256;
+  while (SR < 64 * c + CH) SR <<= 1;
+  size_t lds = (size_t)SR * 8 + (size_t)TABN * sizeof(RowParam) + (size_t)H * 64 * 20 + 16;
+  int per_cu = (int)((160 * 1024) / lds);
+  if (per_cu > 16) per_cu = 16;
+  if (per_cu < 1) per_cu = 1;
+  int64_t slots = ctx->slots_override > 0 ? ctx->slots_override : (int64_t)ctx->num_cus * per_cu;
+  if (slots > a.n_reads) slots = a.n_reads;
+  const int64_t spill_stride = ((int64_t)max_steps + 2 * PF) * 64;
+  const int64_t L_stride = (int64_t)max_steps + 2 * PF + 2;
+  const int64_t bp_stride = (int64_t)((max_steps + 31) / 32 + 1) * 64;
+  const int64_t cap = (int64_t)48 << 30;
+  while (slots > 1 && slots * spill_stride * 8 > cap) slots /= 2;
+  int rc = nvk_ws_reserve(ctx, WS_SPILL, (size_t)slots * spill_stride * 8);
+  if (rc) return rc;
+  rc = nvk_ws_reserve(ctx, WS_STAGE, (size_t)slots * L_stride * 4);
+  if (rc) return rc;
+  rc = nvk_ws_reserve(ctx, WS_BP, (size_t)slots * bp_stride * 4);
+  if (rc) return rc;
+  rc = nvk_ws_reserve(ctx, WS_MISC, 256);
+  if (rc) return rc;
+  int *counter = (int *)ctx->ws[WS_MISC];
+  int *d_retry = counter + 2;
+  NVK_HIP(hipMemsetAsync(counter, 0, 4 * sizeof(int), ctx->stream));
+
+  Align3Args g;
+  g.metas = metas;
+  g.rows = rows;
+  g.signal = a.signal;
+  g.spill_v = (double *)ctx->ws[WS_SPILL];
+  g.spill_L = (int32_t *)ctx->ws[WS_STAGE];
+  g.bp = (uint32_t *)ctx->ws[WS_BP];
+  g.spill_stride = spill_stride;
+  g.L_stride = L_stride;
+  g.bp_stride = bp_stride;
+  g.n_reads = (int)a.n_reads;
+  g.counter = counter;
+  g.H = H;
+  g.SR = SR;
+  g.transitions = transitions;
+  g.c_cap = ALIGN1_C_CAP;
+  g.n_retry = d_retry;
+  g.out_events = out_events;
+  g.out_status = out_status;
+
+  void (*kern)(Align3Args) = nullptr;
+  switch (mel) {
+    case 0: kern = align3_kernel<0>; break;
+    case 1: kern = align3_kernel<1>; break;
+    case 2: kern = align3_kernel<2>; break;
+    case 3: kern = align3_kernel<3>; break;
+    default: kern = align3_kernel<4>; break;
+  }
+  {
+    TimerScope ts(ctx, NVK_K_ALIGN);
+    hipLaunchKernelGGL(kern, dim3((unsigned)slots), dim3(64), lds, ctx->stream, g);
+  }
+  NVK_HIP(hipGetLastError());
+  NVK_HIP(hipMemcpyAsync(n_retry, d_retry, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  NVK_HIP(hipStreamSynchronize(ctx->stream));
+  // bytes the sweeps stream through HBM: 8 B written + 8 B read per (step, lane) + scales + bits
+  ctx->last_spill_bytes = (int64_t)tot.steps * 64 * 16 + (int64_t)tot.steps * 8 + (int64_t)tot.steps * 8 * 2;
+  return NVK_OK;
+}

@@ -172,6 +172,8 @@ struct Align2Plan {
   AlignLane *fwd;  // [total_ref + n] lanes of the prefix sweep
   AlignLane *rev;  // [total_ref + n] lanes of the mirrored suffix sweep
 };
+// internal per-read status of the scaled-double kernel: the exact kernel must redo this read
+constexpr int NVK_READ_RETRY_INTERNAL = 2;
 constexpr int ALIGN1_C_CAP = 3;  // skew served by the main launch of the one-read-per-wave kernel
 constexpr int ALIGN2_C_CAP = 3;  // skew served by the main launch of the paired kernel
 int launch_plan_align2(nvk_ctx *ctx, const DeviceModel &dm, const BatchArgs &a, int transitions,
@@ -179,6 +181,14 @@ int launch_plan_align2(nvk_ctx *ctx, const DeviceModel &dm, const BatchArgs &a, 
                        PlanTotals *totals);
 int launch_align2(nvk_ctx *ctx, const BatchArgs &a, int transitions, const Align2Plan &pl,
                   const PlanTotals &tot, int32_t *out_events, int32_t *out_status);
+// only_retry != 0: serve only the reads whose out_status is NVK_READ_RETRY_INTERNAL
+int launch_align_retry(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadMeta *metas,
+                       const RowParam *rows, const PlanTotals &tot, int32_t *out_events,
+                       int32_t *out_status);
+// scaled-double kernel (kernels_align3.hip); *n_retry = reads it handed to the exact kernel
+int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadMeta *metas,
+                  const RowParam *rows, const PlanTotals &tot, int32_t *out_events,
+                  int32_t *out_status, int *n_retry);
 int launch_expected(nvk_ctx *ctx, const DeviceModel &dm, int64_t n_reads, int64_t total_ref,
                     const int32_t *reference, const int64_t *ref_off, const int32_t *cb,
                     const int64_t *cb_off, const int32_t *ca, const int64_t *ca_off, double *out);

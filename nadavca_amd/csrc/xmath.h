@@ -42,6 +42,25 @@ __device__ __forceinline__ double exp2_frac(double f) {
   return fma(b2, f8, fma(b1, f4, b0));
 }
 
+// The same polynomial in Horner form: every step is v_fma_f64 with the coefficient as a scalar
+// operand, so no coefficient ever occupies a VGPR (the Estrin form above costs six v_mov_b64 per
+// evaluation on gfx950).  Used where instruction count, not latency, is the limit.
+// Max relative error 1.6e-16 (tools/gen_exp2_poly.py).
+__device__ __forceinline__ double exp2_frac_horner(double f) {
+  double p = 0x1.e9ec1fcb69a7fp-32;
+  p = fma(p, f, 0x1.e6228acd1c6e5p-28);
+  p = fma(p, f, 0x1.b524ebd13a55fp-24);
+  p = fma(p, f, 0x1.62bfc2c86d700p-20);
+  p = fma(p, f, 0x1.ffcbfc6da6ed1p-17);
+  p = fma(p, f, 0x1.430913112c61bp-13);
+  p = fma(p, f, 0x1.5d87fe78a3f9cp-10);
+  p = fma(p, f, 0x1.3b2ab6fb9f1a5p-7);
+  p = fma(p, f, 0x1.c6b08d704a0c6p-5);
+  p = fma(p, f, 0x1.ebfbdff82c5aep-3);
+  p = fma(p, f, 0x1.62e42fefa39efp-1);
+  return fma(p, f, 1.0);
+}
+
 // 2^y for a base-2 log density y (finite or -inf) as an extended number, mantissa in
 // [2^-0.5, 2^0.5]
 __device__ __forceinline__ X from_log2(double y) {
