@@ -71,15 +71,44 @@ __device__ __forceinline__ void load_tab_block(RowParam *tab, const RowParam *ro
   if (r >= 0 && r < T) tab[r & (TABN - 1)] = rows[r];
 }
 
-// e(x) * 2^dshift as a plain double; constant rows have mc2 == 0, impossible ones ac2 == -inf.
-// ac2/mc2: the reference's constants (kmer_model.cpp:9-12,48-50) times log2(e).
-__device__ __forceinline__ double density(double x, double mean, double ac2, double mc2, int dshift) {
-  double d = x - mean;
-  double y = fmax(ac2 - d * d * mc2, xm::YCLAMP);
-  double k = rint(y);
-  double p = xm::exp2_frac(y - k);
-  double e = ldexp(p, (int)k + dshift);
-  return (y <= xm::YCLAMP * 0.5) ? 0.0 : e;
+// e(x) * 2^dshift as a plain double.  `ac`/`mc` are the reference's constants
+// (kmer_model.cpp:9-12,48-50) times 256*log2(e), so y = 256 * log2 e(x); constant rows have mc == 0
+// and impossible ones (ac == -inf) are loaded as ac = -2^30, mc = 0, whose 2^(-2^22) flushes to an
+// exact 0.  2^(y/256) = 2^(k) * 2^(j/256) * 2^(g/256), j from a 256-entry LDS table, the last factor
+// a degree-4 Taylor polynomial (|g| <= 1/2: error <= 2.2e-16, i.e. rounding level).  A non-finite
+// sample gives NaN, which the caller's range check turns into a retry by the exact kernel.
+constexpr int ETN = 256;
+// v_fma_f64 with three VGPR operands: keeps the compiler from choosing v_fmac + a 64-bit register
+// copy of the coefficient per term
+__device__ __forceinline__ double fma_vvv(double a, double b, double c) {
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+#define DENS_SCALE (256.0 * 0x1.71547652b82fep+0)
+__device__ __forceinline__ double density(double x, double mean, double ac, double mc, int dshift,
+                                          const double *etab) {
+  const double d = x - mean;
+  const double y = fma(-(d * d), mc, ac);
+  const double kk = rint(y);
+  const double gq = y - kk;
+  const int ki = (int)kk;
+  const double tj = etab[ki & (ETN - 1)];
+  double p = fma_vvv(gq, 0x1.3b2ab6fba4e77p-39, 0x1.c6b08d704a0c0p-29);
+  p = fma_vvv(p, gq, 0x1.ebfbdff82c58fp-19);
+  p = fma_vvv(p, gq, 0x1.62e42fefa39efp-9);
+  p = fma(p, gq, 1.0);
+  return ldexp(tj * p, (ki >> 8) + dshift);
+}
+
+__device__ __forceinline__ void load_density_consts(const RowParam &o, double &mean, double &ac, double &mc) {
+  mean = o.mean;
+  ac = o.ac * DENS_SCALE;
+  mc = o.mc * DENS_SCALE;
+  if (!(ac > -0x1.0p+900)) {
+    ac = -0x1.0p+30;
+    mc = 0.0;
+  }
 }
 
 template <int MEL>
@@ -92,9 +121,9 @@ __device__ __forceinline__ double emission_product(double e, double e1, double e
   return P;
 }
 
-__device__ __forceinline__ int wave_max_i(int v) {
+__device__ __forceinline__ int wave_max_i(int v) {  // result in a scalar register
   for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d, 64));
-  return v;
+  return __builtin_amdgcn_readfirstlane(v);
 }
 
 // running scale: L(u) = L(u-1) + delta_u; delta is nonzero only on rescale steps
@@ -108,11 +137,12 @@ struct Scale {
 template <int MEL>
 __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  double *ring = reinterpret_cast<double *>(smem);
+  double *etab = reinterpret_cast<double *>(smem);
+  double *ring = etab + ETN;
   RowParam *tab = reinterpret_cast<RowParam *>(ring + g.SR);
-  double *hist = reinterpret_cast<double *>(tab + TABN);
-  double *dhist = hist + (size_t)g.H * 64;
-  int *ghist = reinterpret_cast<int *>(dhist + (size_t)g.H * 64);
+  double *hist = reinterpret_cast<double *>(tab + TABN);     // reverse sweep: suffix values
+  double2 *hist2 = reinterpret_cast<double2 *>(tab + TABN);  // forward sweep: (prefix, path score)
+  int *ghist = reinterpret_cast<int *>(hist2 + (size_t)g.H * 64);
   int *s_read = ghist + (size_t)g.H * 64;
 
   const int lane = threadIdx.x;
@@ -122,6 +152,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
   uint32_t *bp = g.bp + (size_t)blockIdx.x * g.bp_stride;
 
   for (int q = lane; q < g.SR; q += 64) ring[q] = 0.0;
+  for (int q = lane; q < ETN; q += 64) etab[q] = exp2((double)q * (1.0 / ETN));
 
   while (true) {
     __syncthreads();
@@ -164,17 +195,20 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
         load_tab_block(tab, rows, loaded_lo, T, lane);
       }
       __syncthreads();
+      // Lanes without a row keep bs = hi = -big: never active, never finished.  For the other
+      // rows `hi` already folds the "predecessor column exists" test (i + mel <= N).
       double mean = 0, ac2 = 0, mc2 = 0;
-      int bs = 0x40000000, hi = -0x40000000, pbs = 0, pbe = -1, melr = 0;
+      int bs = -0x40000000, hi = -0x40000000, pbs = 0, pbe = -1, melr = 0;
       bool is_init = false;
       if (r >= 0) {
         const RowParam &o = tab[r & (TABN - 1)];
-        mean = o.mean; ac2 = o.ac * xm::LOG2E; mc2 = o.mc * xm::LOG2E; melr = o.mel;
+        load_density_consts(o, mean, ac2, mc2); melr = o.mel;
         bs = o.bs; hi = o.hi;
         is_init = (r == top);
         if (!is_init) {
           const RowParam &p = tab[(r + 1) & (TABN - 1)];
           pbs = p.bs; pbe = p.be;
+          hi = min(hi, N - melr);
         }
       }
       int i = t_max - c * r;
@@ -191,8 +225,9 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
       }
       __syncthreads();
       Scale sc{0, -0x40000000, 0, 0};
-      double e = density(ring[i & RM], mean, ac2, mc2, 0);
+      double e = density(ring[i & RM], mean, ac2, mc2, 0, etab);
       int su = 0, sA = sA0, sB = sB0;
+      bool init_live = true;  // (uniform) the last row is still being swept
 
       for (int u = 0; u < n_steps; ++u) {
         const int t = t_max - u;
@@ -203,7 +238,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
           sc.d_last = sc.d_next;
           sc.d_next = 0;
         }
-        bool fin = (r >= 0) && (i < bs);
+        bool fin = (i < bs);
         if (__any(fin)) {
           int nr = r - 64;
           if (__any(fin && nr >= 0 && (nr >> 6) < loaded_lo)) {
@@ -218,15 +253,16 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
             if (r >= 0) {
               const RowParam &o = tab[r & (TABN - 1)];
               const RowParam &p = tab[(r + 1) & (TABN - 1)];
-              mean = o.mean; ac2 = o.ac * xm::LOG2E; mc2 = o.mc * xm::LOG2E; melr = o.mel;
-              bs = o.bs; hi = o.hi; pbs = p.bs; pbe = p.be;
+              load_density_consts(o, mean, ac2, mc2); melr = o.mel;
+              bs = o.bs; hi = min(o.hi, N - melr); pbs = p.bs; pbe = p.be;
               is_init = false;
-              e = density(ring[i & RM], mean, ac2, mc2, (sc.u_last == u) ? sc.d_last : 0);
+              e = density(ring[i & RM], mean, ac2, mc2, (sc.u_last == u) ? sc.d_last : 0, etab);
             } else {
-              hi = -0x40000000; bs = 0x40000000;
+              hi = -0x40000000; bs = -0x40000000;
             }
           }
-          while (r_old >= 0 && __shfl(r, r_old & 63, 64) != r_old) r_old--;
+          while (r_old >= 0 && __builtin_amdgcn_readlane(r, r_old & 63) != r_old) r_old--;
+          init_live = init_live && (__builtin_amdgcn_readlane(r, top & 63) == top);
         }
         if (r_old >= 0) {
           int need_min = t - 1 - c * r_old;
@@ -245,7 +281,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
         const int shT = (age < c) ? sc.d_last : 0;                       // D = c      (mel 0 rows)
         const int shE = (age >= MEL && age < c + MEL) ? sc.d_last : 0;  // D = c+MEL  (beyond the densities' own shifts)
         // ---- the cell (r, i): out = P * pred[i + mel] + e(s[i]) * out[i + 1]
-        const bool active = (r >= 0) && (i <= hi) && (i >= bs);
+        const bool active = (i <= hi) && (i >= bs);
         double P = emission_product<MEL>(e, e1, e2, e3);
         P = (melr == 0) ? 1.0 : P;
         const int j = i + melr;
@@ -253,18 +289,25 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
         double pv = hist[hs];
         pv = (j >= pbs && j <= pbe) ? pv : 0.0;
         double t1 = P * pv;
-        if ((shT | shE) != 0) t1 = ldexp(t1, melr == 0 ? shT : shE);
-        const double t2 = e * prev;
-        double o = t1 + t2;
-        const bool valid = active && (j <= N);
-        o = valid ? o : 0.0;
-        if (is_init) o = active ? ldexp(1.0, sc.L) : 0.0;
+        if ((shT | shE) != 0) {  // uniform and rare: keep it a branch
+          asm volatile("" ::: "memory");
+          t1 = ldexp(t1, melr == 0 ? shT : shE);
+        }
+        double o = fma(e, prev, t1);
+        o = active ? o : 0.0;
+        if (init_live) {
+          asm volatile("" ::: "memory");
+          if (is_init) o = active ? ldexp(1.0, sc.L) : 0.0;
+        }
         // Cells far off the likely path are thousands of bits below the wave's largest value and
         // flush to zero here; that cannot change any value that matters (their contributions are
         // below 2^-53 of it in exact arithmetic too).  Overflow / NaN must never happen.
         suspect |= !(o <= HUGE_V);
         prev = o;
-        if (r == 0 && o != 0.0) kmax = max(kmax, __builtin_amdgcn_frexp_exp(o) - sc.L);
+        if (__builtin_amdgcn_readfirstlane(r) == 0) {  // row 0 lives on lane 0; only its kmax is read
+          asm volatile("" ::: "memory");
+          if (o != 0.0) kmax = max(kmax, __builtin_amdgcn_frexp_exp(o) - sc.L);
+        }
         hist[su * 64 + lane] = o;
         spill_v[(size_t)(t - t_min) * 64 + lane] = o;
         if (lane == 0) spill_L[t - t_min] = sc.L;
@@ -276,7 +319,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
         }
         i -= 1;
         e3 = e2; e2 = e1; e1 = e;
-        e = density(ring[i & RM], mean, ac2, mc2, sc.d_next);
+        e = density(ring[i & RM], mean, ac2, mc2, sc.d_next, etab);
         su = (su + 1 == H) ? 0 : su + 1;
         sA = (sA + 1 == H) ? 0 : sA + 1;
         sB = (sB + 1 == H) ? 0 : sB + 1;
@@ -295,8 +338,10 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
       int loaded_hi = 0;
       load_tab_block(tab, rows, 0, T, lane);
       __syncthreads();
+      // Lanes without a row keep lo = be = +big: never active, never finished.  For the other rows
+      // `lo` already folds the "predecessor column exists" test (i - mel >= 0).
       double mean = 0, ac2 = 0, mc2 = 0;
-      int bs = 0, be = -0x40000000, lo = 0x40000000, pbs = 0, pbe = -1, melr = 0;
+      int bs = 0, be = 0x40000000, lo = 0x40000000, pbs = 0, pbe = -1, melr = 0;
       bool is_init = false;
       if (r < T) {
         const RowParam &o = tab[r & (TABN - 1)];
@@ -304,16 +349,17 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
         is_init = (r == 0);
         if (!is_init) {
           const RowParam &p = tab[(r - 1) & (TABN - 1)];
-          mean = p.mean; ac2 = p.ac * xm::LOG2E; mc2 = p.mc * xm::LOG2E; melr = p.mel;
+          load_density_consts(p, mean, ac2, mc2); melr = p.mel;
           pbs = p.bs; pbe = p.be;
+          lo = max(lo, melr);
         }
       }
       int i = t_min - c * r;
       double prev = 0.0, e1 = 1.0, e2 = 1.0, e3 = 1.0;
       // path DP state of the row: running maximum of the previous row's scores (raw, as received,
       // and normalised by 2^rho), its tolerance margin, the row's accumulated exponent G
-      double best = 0.0, bestn = 0.0, bthr = 0.0;
-      int Gb = 0, G = 0;  // scale of `best` as received; scale of this row's scores
+      double bestn = 0.0, bthr = 0.0;
+      int G = 0;  // scale of bestn, and so of this row's scores
       // Flush detector.  In a banded forward-backward pass every allowed path crosses every row
       // exactly once, so sum_i prefix[r][i] * suffix[r][i] is the SAME total for every row r.
       // Cells far below the wave's scale flush to zero here; if that ever removes mass that
@@ -331,8 +377,9 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
       }
       __syncthreads();
       Scale sc{0, -0x40000000, 0, 0};
-      double e = density(ring[(i - 1) & RM], mean, ac2, mc2, 0);
+      double e = density(ring[(i - 1) & RM], mean, ac2, mc2, 0, etab);
       int su = 0, sA = sA0, sB = sB0;
+      bool init_live = true;  // (uniform) row 0 is still being swept
 
       double cur_v[PF];
       int cur_L[PF];
@@ -354,7 +401,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
               sc.d_last = sc.d_next;
               sc.d_next = 0;
             }
-            bool fin = (r < T) && (i > be);
+            bool fin = (i > be);
             if (__any(fin)) {
               int nr = r + 64;
               if (__any(fin && nr < T && (nr >> 6) > loaded_hi)) {
@@ -369,20 +416,21 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
                 r = nr;
                 i -= 64 * c;
                 prev = 0.0;
-                best = 0.0; bestn = 0.0; bthr = 0.0; Gb = 0; G = 0;
+                bestn = 0.0; bthr = 0.0; G = 0;
                 if (r < T) {
                   const RowParam &o = tab[r & (TABN - 1)];
                   const RowParam &p = tab[(r - 1) & (TABN - 1)];
-                  bs = o.bs; be = o.be; lo = o.lo;
-                  mean = p.mean; ac2 = p.ac * xm::LOG2E; mc2 = p.mc * xm::LOG2E; melr = p.mel;
+                  load_density_consts(p, mean, ac2, mc2); melr = p.mel;
+                  bs = o.bs; be = o.be; lo = max(o.lo, melr);
                   pbs = p.bs; pbe = p.be;
                   is_init = false;
-                  e = density(ring[(i - 1) & RM], mean, ac2, mc2, (sc.u_last == u) ? sc.d_last : 0);
+                  e = density(ring[(i - 1) & RM], mean, ac2, mc2, (sc.u_last == u) ? sc.d_last : 0, etab);
                 } else {
-                  lo = 0x40000000; be = -0x40000000;
+                  lo = 0x40000000; be = 0x40000000;
                 }
               }
-              while (r_old < T && __shfl(r, r_old & 63, 64) != r_old) r_old++;
+              while (r_old < T && __builtin_amdgcn_readlane(r, r_old & 63) != r_old) r_old++;
+              init_live = init_live && (__builtin_amdgcn_readfirstlane(r) == 0);
             }
             if (r_old < T) {
               int need_max = t + 1 - c * r_old - 1;
@@ -400,25 +448,29 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
             const int shT = (age < c) ? sc.d_last : 0;
             const int shE = (age >= MEL && age < c + MEL) ? sc.d_last : 0;
             // ---- the cell (r, i): out = P * pred[i - mel] + e(s[i-1]) * out[i - 1]
-            const bool active = (r < T) && (i >= lo) && (i <= be);
+            const bool active = (i >= lo) && (i <= be);
             const bool in_band = active && (i >= bs);
             double P = emission_product<MEL>(e, e1, e2, e3);
             P = (melr == 0) ? 1.0 : P;
             const int j = i - melr;
             const bool ok = (j >= pbs) && (j <= pbe);
             const int hs = (melr == 0 ? sB : sA) * 64 + ((lane - 1) & 63);
-            double pv = hist[hs];
-            double dv = dhist[hs];
+            const double2 hv = hist2[hs];
+            double pv = hv.x, dv = hv.y;
             const int Gin = ghist[hs];
             pv = ok ? pv : 0.0;
             dv = ok ? dv : 0.0;
             double t1 = P * pv;
-            if ((shT | shE) != 0) t1 = ldexp(t1, melr == 0 ? shT : shE);
-            const double t2 = e * prev;
-            double o = t1 + t2;
-            const bool valid = active && (i >= melr);
-            o = valid ? o : 0.0;
-            if (is_init) o = in_band ? ldexp(1.0, sc.L) : 0.0;
+            if ((shT | shE) != 0) {  // uniform and rare: keep it a branch
+              asm volatile("" ::: "memory");
+              t1 = ldexp(t1, melr == 0 ? shT : shE);
+            }
+            double o = fma(e, prev, t1);
+            o = active ? o : 0.0;
+            if (init_live) {
+              asm volatile("" ::: "memory");
+              if (is_init) o = in_band ? ldexp(1.0, sc.L) : 0.0;
+            }
             suspect |= !(o <= HUGE_V);
             prev = o;
             // ---- posterior of the cell, on the scale 2^-K:  post = prefix * suffix
@@ -428,23 +480,23 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
             rsum += post;
             // ---- path step (node.cpp:52-91): running maximum of the previous row, strict '>' at the
             // resolution of the reference's log-doubles (xm::gt_tol): margin = best * |exponent| * 2^-52
-            // Scores are (double, integer scale): stored = true * 2^scale.  The running maximum keeps
-            // the scale it arrived with; an incoming score is brought onto it before comparing
-            // (far below -> 0, far above -> inf, both compare correctly).
-            const double dva = ldexp(dv, (best == 0.0) ? 0 : Gb - Gin);
-            const bool upd = active && (dva - best > bthr);
+            // Scores are (double, integer scale): stored = true * 2^scale.  The running maximum is kept
+            // normalised (bestn in [0.5,1), scale G); an incoming score is brought onto that scale
+            // before comparing (far below -> 0, far above -> inf, both compare correctly).
+            const double dva = ldexp(dv, (bestn == 0.0) ? 0 : G - Gin);
+            const bool upd = active && (dva - bestn > bthr);
             if (upd) {
-              const int ex = __builtin_amdgcn_frexp_exp(dv);
-              best = dv;
-              Gb = Gin;
-              bestn = __builtin_amdgcn_frexp_mant(dv);  // dv * 2^-ex
-              G = Gin - ex;                             // scale of bestn * post
-              bthr = dv * ((double)abs(ex - Gin) * 0x1.0p-52);
+              bestn = __builtin_amdgcn_frexp_mant(dv);         // in [0.5, 1)
+              G = Gin - __builtin_amdgcn_frexp_exp(dv);        // its scale; -G = true exponent
+              bthr = bestn * ((double)abs(G) * 0x1.0p-52);
             }
             bits |= upd ? (1u << (u & 31)) : 0u;
-            double dpv = is_init ? post : bestn * post;
-            dpv = in_band ? dpv : 0.0;
-            const int Gd = is_init ? 0 : G;
+            double dpv = bestn * post;  // post is already 0 outside the band
+            int Gd = G;
+            if (init_live) {
+              asm volatile("" ::: "memory");
+              if (is_init) { dpv = post; Gd = 0; }
+            }
             if (__any(r == top && in_band)) {
               const double da = ldexp(dpv, (fbest == 0.0) ? 0 : fG - Gd);
               if (r == top && (da - fbest > fthr)) {
@@ -454,8 +506,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
                 fthr = dpv * ((double)abs(__builtin_amdgcn_frexp_exp(dpv) - Gd) * 0x1.0p-52);
               }
             }
-            hist[su * 64 + lane] = o;
-            dhist[su * 64 + lane] = dpv;
+            hist2[su * 64 + lane] = make_double2(o, dpv);
             ghist[su * 64 + lane] = Gd;
             if ((u & 31) == 31 || u == n_steps - 1) {
               bp[(size_t)(u >> 5) * 64 + lane] = bits;
@@ -472,7 +523,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
             }
             i += 1;
             e3 = e2; e2 = e1; e1 = e;
-            e = density(ring[(i - 1) & RM], mean, ac2, mc2, sc.d_next);
+            e = density(ring[(i - 1) & RM], mean, ac2, mc2, sc.d_next, etab);
             su = (su + 1 == H) ? 0 : su + 1;
             sA = (sA + 1 == H) ? 0 : sA + 1;
             sB = (sB + 1 == H) ? 0 : sB + 1;
@@ -558,7 +609,7 @@ int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadM
   const int H = c + mel + 1;
   int SR = 256;
   while (SR < 64 * c + CH) SR <<= 1;
-  size_t lds = (size_t)SR * 8 + (size_t)TABN * sizeof(RowParam) + (size_t)H * 64 * 20 + 16;
+  size_t lds = (size_t)ETN * 8 + (size_t)SR * 8 + (size_t)TABN * sizeof(RowParam) + (size_t)H * 64 * 20 + 16;
   int per_cu = (int)((160 * 1024) / lds);
   if (per_cu > 16) per_cu = 16;
   if (per_cu < 1) per_cu = 1;
