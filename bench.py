@@ -171,7 +171,8 @@ def main():
                        'samples_per_read': round(dbatch.total_signal / n_reads, 1),
                        'bases_per_read': round(dbatch.total_ref / n_reads, 1), 'bandwidth': bandwidth,
                        'min_event_length': mel, 'kmer_model': 'packaged 6-mer', 'reads_ok': n_ok,
-                       'band_cells_per_read': round(stats['band_cells'] / n_reads, 1)},
+                       'band_cells_per_read': round(stats['band_cells'] / n_reads, 1),
+                       'reads_redone_exact': stats['reads_redone_exact']},
         }
         kname = 'align' if args.workload == 'cfg2_align' else 'ell_hyp'
         ms, launches = timing[kname]

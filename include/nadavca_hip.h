@@ -88,6 +88,9 @@ int nvk_timing_read(nvk_ctx *ctx, int kernel_id, double *total_ms, int64_t *laun
  * wavefront steps, and the workspace bytes the sweep kernels streamed */
 int nvk_last_batch_stats(nvk_ctx *ctx, int64_t *band_cells, int64_t *wave_steps,
                          int64_t *spill_bytes);
+/* reads of the last nvk_refine_alignment_batch[_dev] call that left the fast kernel's number range
+ * and were recomputed by the exact kernel (results are the same either way; this is a cost figure) */
+int nvk_last_retry_count(nvk_ctx *ctx, int64_t *n_reads);
 
 /* replaces dtw.KmerModel(k, central_position, alphabet_size, mean, sigma)
  * (dtwmodule.cpp:12-13, kmer_model.cpp:6-14).  mean/sigma: host f64[n], n = alphabet^k */

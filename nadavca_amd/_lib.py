@@ -43,6 +43,7 @@ SIGNATURES = {
     'nvk_timing_reset': (_int, [_vp]),
     'nvk_timing_read': (_int, [_vp, _int, C.POINTER(_dbl), C.POINTER(_i64)]),
     'nvk_last_batch_stats': (_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
+    'nvk_last_retry_count': (_int, [_vp, C.POINTER(_i64)]),
     'nvk_model_create': (_int, [_vp, _int, _int, _int, _vp, _vp, _i64, C.POINTER(_vp)]),
     'nvk_model_destroy': (None, [_vp]),
     'nvk_model_info': (_int, [_vp, C.POINTER(_int), C.POINTER(_int), C.POINTER(_int)]),
@@ -131,7 +132,9 @@ class Context:
         a, b, c = _i64(), _i64(), _i64()
         check(self._lib.nvk_last_batch_stats(self.handle, C.byref(a), C.byref(b), C.byref(c)),
               'nvk_last_batch_stats')
-        return dict(band_cells=a.value, wave_steps=b.value, spill_bytes=c.value)
+        d = _i64()
+        check(self._lib.nvk_last_retry_count(self.handle, C.byref(d)), 'nvk_last_retry_count')
+        return dict(band_cells=a.value, wave_steps=b.value, spill_bytes=c.value, reads_redone_exact=d.value)
 
     def close(self):
         if getattr(self, 'handle', None):

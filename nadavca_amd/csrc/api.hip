@@ -166,6 +166,12 @@ extern "C" int nvk_last_batch_stats(nvk_ctx *ctx, int64_t *band_cells, int64_t *
   return NVK_OK;
 }
 
+extern "C" int nvk_last_retry_count(nvk_ctx *ctx, int64_t *n_reads) {
+  if (!ctx || !n_reads) return NVK_ERR_INVALID;
+  *n_reads = ctx->last_retries;
+  return NVK_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // model
 // ---------------------------------------------------------------------------------------------
@@ -468,6 +474,7 @@ extern "C" int nvk_refine_alignment_batch_dev(
   //   NADAVCA_ALIGN_KERNEL=1   kernels_align.hip only (mantissa+exponent per value)
   //   NADAVCA_ALIGN_KERNEL=2   kernels_align2.hip (fused lanes, two reads per wave)
   const char *force = getenv("NADAVCA_ALIGN_KERNEL");
+  ctx->last_retries = 0;
   bool use_v1 = !(force && force[0] == '2');
   if (!use_v1) {
     const int64_t n = n_reads, nrow = total_ref + n;
@@ -504,6 +511,7 @@ extern "C" int nvk_refine_alignment_batch_dev(
       int n_retry = 0;
       rc = launch_align3(ctx, a, model_transitions ? 1 : 0, metas, rows, tot, out_events, out_status,
                          &n_retry);
+      ctx->last_retries = n_retry;
       if (rc == NVK_ERR_UNSUPPORTED) exact_all = true;
       else if (rc) return rc;
       else if (n_retry > 0 && !getenv("NADAVCA_ALIGN3_NORETRY")) {  // (debug switch: leave flags visible)

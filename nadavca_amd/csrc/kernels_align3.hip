@@ -32,9 +32,9 @@
 namespace {
 
 constexpr int CH = 128;     // signal refill chunk (samples)
-constexpr int TABN = 128;   // row-table window (two 64-row blocks)
 constexpr int PF = 4;       // forward sweep: spill prefetch depth (steps)
 constexpr int RS = 16;      // rescale period (steps); must exceed c + mel
+constexpr int GBIG = 1 << 24;  // scale of an empty running maximum (see the path step)
 constexpr int TARGET = 250; // exponent the largest live value is moved to
 #define HUGE_V 0x1.0p+900
 #define MASS_TOL 1e-9          // allowed relative spread of the rows' posterior mass
@@ -45,9 +45,25 @@ constexpr int TARGET = 250; // exponent the largest live value is moved to
     __builtin_amdgcn_wave_barrier();                       \
   } while (0)
 
+// What one lane needs to sweep one row, per sweep direction: the density of the step it applies
+// (forward: r-1 -> r, reverse: r -> r+1) with ac/mc pre-scaled for density(), its own span and the
+// band of the row it receives from.  Derived from the planner's RowParam table by lane3_kernel so
+// that a lane can fetch its next row (64 rows on) with three 16-byte loads issued one row ahead and
+// held in registers: no row table in LDS, which is what limits the waves per CU.
+struct __attribute__((aligned(16))) Lane3 {
+  double mean, ac, mc;
+  int32_t bs;        // band start of the lane's row
+  int32_t end;       // forward: band end `be`; reverse: span end `hi` (with i + mel <= N folded in)
+  int32_t lo;        // forward: span start (with i - mel >= 0 folded in); reverse: unused
+  int32_t pbs, pbe;  // band of the row the lane receives from (empty for the sweep's first row)
+  int32_t mel;       // min event length of the applied step
+};
+static_assert(sizeof(Lane3) == 48, "Lane3 layout");
+
 struct Align3Args {
   const ReadMeta *metas;
-  const RowParam *rows;
+  const Lane3 *fwdl;
+  const Lane3 *revl;
   const double *signal;
   double *spill_v;   // suffix values, [slot][step][lane], scaled by 2^L(step)
   int32_t *spill_L;  // [slot][step] running log-scale of the reverse sweep
@@ -65,11 +81,6 @@ struct Align3Args {
   int32_t *out_status;
 };
 
-__device__ __forceinline__ void load_tab_block(RowParam *tab, const RowParam *rows, int blk, int T,
-                                               int lane) {
-  int r = blk * 64 + lane;
-  if (r >= 0 && r < T) tab[r & (TABN - 1)] = rows[r];
-}
 
 // e(x) * 2^dshift as a plain double.  `ac`/`mc` are the reference's constants
 // (kmer_model.cpp:9-12,48-50) times 256*log2(e), so y = 256 * log2 e(x); constant rows have mc == 0
@@ -101,15 +112,60 @@ __device__ __forceinline__ double density(double x, double mean, double ac, doub
   return ldexp(tj * p, (ki >> 8) + dshift);
 }
 
-__device__ __forceinline__ void load_density_consts(const RowParam &o, double &mean, double &ac, double &mc) {
-  mean = o.mean;
-  ac = o.ac * DENS_SCALE;
-  mc = o.mc * DENS_SCALE;
-  if (!(ac > -0x1.0p+900)) {
-    ac = -0x1.0p+30;
-    mc = 0.0;
+__device__ __forceinline__ void set_density_consts(Lane3 &l, const RowParam &o) {
+  l.mean = o.mean;
+  l.ac = o.ac * DENS_SCALE;
+  l.mc = o.mc * DENS_SCALE;
+  if (!(l.ac > -0x1.0p+900)) {
+    l.ac = -0x1.0p+30;
+    l.mc = 0.0;
+  }
+  l.mel = o.mel;
+}
+
+// one block per read: RowParam rows -> per-sweep lane records
+__global__ __launch_bounds__(256) void lane3_kernel(const ReadMeta *metas, const RowParam *rows,
+                                                    Lane3 *fwdl, Lane3 *revl, int n_reads) {
+  const int rd = blockIdx.x;
+  if (rd >= n_reads) return;
+  const ReadMeta m = metas[rd];
+  if (m.status != NVK_READ_OK) return;
+  const RowParam *rw = rows + m.row_off;
+  const int T = m.T, N = m.N, top = T - 1;
+  for (int r = threadIdx.x; r < T; r += blockDim.x) {
+    const RowParam o = rw[r];
+    Lane3 f, b;
+    // forward: applies step r-1 -> r
+    f.bs = o.bs; f.end = o.be; f.lo = o.lo;
+    if (r > 0) {
+      const RowParam p = rw[r - 1];
+      set_density_consts(f, p);
+      f.pbs = p.bs; f.pbe = p.be;
+      f.lo = max(o.lo, p.mel);
+    } else {
+      f.mean = 0.0; f.ac = 0.0; f.mc = 0.0; f.mel = 0; f.pbs = 0; f.pbe = -1;
+    }
+    // reverse: applies step r -> r+1
+    set_density_consts(b, o);
+    b.bs = o.bs; b.lo = 0;
+    if (r < top) {
+      const RowParam q = rw[r + 1];
+      b.pbs = q.bs; b.pbe = q.be;
+      b.end = min(o.hi, N - o.mel);
+    } else {
+      b.pbs = 0; b.pbe = -1;
+      b.end = o.hi;
+    }
+    fwdl[m.row_off + r] = f;
+    revl[m.row_off + r] = b;
   }
 }
+
+#define TAKE_LANE(l)                                                                   \
+  do {                                                                                 \
+    mean = (l).mean; ac2 = (l).ac; mc2 = (l).mc; melr = (l).mel;                       \
+    bs = (l).bs; pbs = (l).pbs; pbe = (l).pbe;                                         \
+  } while (0)
 
 template <int MEL>
 __device__ __forceinline__ double emission_product(double e, double e1, double e2, double e3) {
@@ -139,9 +195,8 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double *etab = reinterpret_cast<double *>(smem);
   double *ring = etab + ETN;
-  RowParam *tab = reinterpret_cast<RowParam *>(ring + g.SR);
-  double *hist = reinterpret_cast<double *>(tab + TABN);     // reverse sweep: suffix values
-  double2 *hist2 = reinterpret_cast<double2 *>(tab + TABN);  // forward sweep: (prefix, path score)
+  double *hist = ring + g.SR;                                   // reverse sweep: suffix values
+  double2 *hist2 = reinterpret_cast<double2 *>(ring + g.SR);   // forward sweep: (prefix, path score)
   int *ghist = reinterpret_cast<int *>(hist2 + (size_t)g.H * 64);
   int *s_read = ghist + (size_t)g.H * 64;
 
@@ -178,7 +233,8 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
     const int t_min = __builtin_amdgcn_readfirstlane(m.t_min);
     const int n_steps = __builtin_amdgcn_readfirstlane(m.n_steps);
     const int t_max = t_min + n_steps - 1;
-    const RowParam *rows = g.rows + m.row_off;
+    const Lane3 *fwdl = g.fwdl + m.row_off;
+    const Lane3 *revl = g.revl + m.row_off;
     const double *sig = g.signal + m.sig_off;
     const int top = T - 1;
     int K = 0;          // true exponent of the largest suffix[0][.]
@@ -188,28 +244,19 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
     // =========================== reverse sweep: suffix rows -> spill ===========================
     {
       int r = top - ((top - lane) & 63);
-      int loaded_lo = top >> 6;
-      load_tab_block(tab, rows, loaded_lo, T, lane);
-      if (loaded_lo > 0) {
-        loaded_lo--;
-        load_tab_block(tab, rows, loaded_lo, T, lane);
-      }
-      __syncthreads();
       // Lanes without a row keep bs = hi = -big: never active, never finished.  For the other
       // rows `hi` already folds the "predecessor column exists" test (i + mel <= N).
       double mean = 0, ac2 = 0, mc2 = 0;
       int bs = -0x40000000, hi = -0x40000000, pbs = 0, pbe = -1, melr = 0;
       bool is_init = false;
+      Lane3 nx;  // the lane's next row (r - 64), fetched one row ahead
+      nx.mean = nx.ac = nx.mc = 0.0; nx.bs = nx.end = nx.lo = nx.pbs = nx.pbe = nx.mel = 0;
       if (r >= 0) {
-        const RowParam &o = tab[r & (TABN - 1)];
-        load_density_consts(o, mean, ac2, mc2); melr = o.mel;
-        bs = o.bs; hi = o.hi;
+        const Lane3 cu = revl[r];
+        TAKE_LANE(cu);
+        hi = cu.end;
         is_init = (r == top);
-        if (!is_init) {
-          const RowParam &p = tab[(r + 1) & (TABN - 1)];
-          pbs = p.bs; pbe = p.be;
-          hi = min(hi, N - melr);
-        }
+        if (r >= 64) nx = revl[r - 64];
       }
       int i = t_max - c * r;
       double prev = 0.0, e1 = 1.0, e2 = 1.0, e3 = 1.0;
@@ -240,22 +287,15 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
         }
         bool fin = (i < bs);
         if (__any(fin)) {
-          int nr = r - 64;
-          if (__any(fin && nr >= 0 && (nr >> 6) < loaded_lo)) {
-            loaded_lo--;
-            load_tab_block(tab, rows, loaded_lo, T, lane);
-            __syncthreads();
-          }
           if (fin) {
-            r = nr;
+            r -= 64;
             i += 64 * c;
             prev = 0.0;
             if (r >= 0) {
-              const RowParam &o = tab[r & (TABN - 1)];
-              const RowParam &p = tab[(r + 1) & (TABN - 1)];
-              load_density_consts(o, mean, ac2, mc2); melr = o.mel;
-              bs = o.bs; hi = min(o.hi, N - melr); pbs = p.bs; pbe = p.be;
+              TAKE_LANE(nx);
+              hi = nx.end;
               is_init = false;
+              if (r >= 64) nx = revl[r - 64];
               e = density(ring[i & RM], mean, ac2, mc2, (sc.u_last == u) ? sc.d_last : 0, etab);
             } else {
               hi = -0x40000000; bs = -0x40000000;
@@ -325,7 +365,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
         sB = (sB + 1 == H) ? 0 : sB + 1;
         WAVE_SYNC();
       }
-      K = __shfl(kmax, 0, 64);
+      K = __builtin_amdgcn_readfirstlane(kmax);
       if (K == -0x40000000) K = 0;
     }
     __syncthreads();
@@ -335,31 +375,26 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
     int fidx = -1, fG = 0;
     {
       int r = lane;
-      int loaded_hi = 0;
-      load_tab_block(tab, rows, 0, T, lane);
-      __syncthreads();
       // Lanes without a row keep lo = be = +big: never active, never finished.  For the other rows
       // `lo` already folds the "predecessor column exists" test (i - mel >= 0).
       double mean = 0, ac2 = 0, mc2 = 0;
       int bs = 0, be = 0x40000000, lo = 0x40000000, pbs = 0, pbe = -1, melr = 0;
       bool is_init = false;
+      Lane3 nx;  // the lane's next row (r + 64), fetched one row ahead
+      nx.mean = nx.ac = nx.mc = 0.0; nx.bs = nx.end = nx.lo = nx.pbs = nx.pbe = nx.mel = 0;
       if (r < T) {
-        const RowParam &o = tab[r & (TABN - 1)];
-        bs = o.bs; be = o.be; lo = o.lo;
+        const Lane3 cu = fwdl[r];
+        TAKE_LANE(cu);
+        be = cu.end; lo = cu.lo;
         is_init = (r == 0);
-        if (!is_init) {
-          const RowParam &p = tab[(r - 1) & (TABN - 1)];
-          load_density_consts(p, mean, ac2, mc2); melr = p.mel;
-          pbs = p.bs; pbe = p.be;
-          lo = max(lo, melr);
-        }
+        if (r + 64 < T) nx = fwdl[r + 64];
       }
       int i = t_min - c * r;
       double prev = 0.0, e1 = 1.0, e2 = 1.0, e3 = 1.0;
       // path DP state of the row: running maximum of the previous row's scores (raw, as received,
       // and normalised by 2^rho), its tolerance margin, the row's accumulated exponent G
       double bestn = 0.0, bthr = 0.0;
-      int G = 0;  // scale of bestn, and so of this row's scores
+      int G = GBIG;  // scale of bestn, and so of this row's scores
       // Flush detector.  In a banded forward-backward pass every allowed path crosses every row
       // exactly once, so sum_i prefix[r][i] * suffix[r][i] is the SAME total for every row r.
       // Cells far below the wave's scale flush to zero here; if that ever removes mass that
@@ -380,6 +415,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
       double e = density(ring[(i - 1) & RM], mean, ac2, mc2, 0, etab);
       int su = 0, sA = sA0, sB = sB0;
       bool init_live = true;  // (uniform) row 0 is still being swept
+      bool top_live = (top < 64); // (uniform) the last row has been started
 
       double cur_v[PF];
       int cur_L[PF];
@@ -403,27 +439,19 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
             }
             bool fin = (i > be);
             if (__any(fin)) {
-              int nr = r + 64;
-              if (__any(fin && nr < T && (nr >> 6) > loaded_hi)) {
-                loaded_hi++;
-                load_tab_block(tab, rows, loaded_hi, T, lane);
-                __syncthreads();
-              }
               if (fin) {
                 smin = fmin(smin, rsum);
                 smax = fmax(smax, rsum);
                 rsum = 0.0;
-                r = nr;
+                r += 64;
                 i -= 64 * c;
                 prev = 0.0;
-                bestn = 0.0; bthr = 0.0; G = 0;
+                bestn = 0.0; bthr = 0.0; G = GBIG;
                 if (r < T) {
-                  const RowParam &o = tab[r & (TABN - 1)];
-                  const RowParam &p = tab[(r - 1) & (TABN - 1)];
-                  load_density_consts(p, mean, ac2, mc2); melr = p.mel;
-                  bs = o.bs; be = o.be; lo = max(o.lo, melr);
-                  pbs = p.bs; pbe = p.be;
+                  TAKE_LANE(nx);
+                  be = nx.end; lo = nx.lo;
                   is_init = false;
+                  if (r + 64 < T) nx = fwdl[r + 64];
                   e = density(ring[(i - 1) & RM], mean, ac2, mc2, (sc.u_last == u) ? sc.d_last : 0, etab);
                 } else {
                   lo = 0x40000000; be = 0x40000000;
@@ -431,6 +459,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
               }
               while (r_old < T && __builtin_amdgcn_readlane(r, r_old & 63) != r_old) r_old++;
               init_live = init_live && (__builtin_amdgcn_readfirstlane(r) == 0);
+              top_live = (__builtin_amdgcn_readlane(r, top & 63) == top);
             }
             if (r_old < T) {
               int need_max = t + 1 - c * r_old - 1;
@@ -475,7 +504,8 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
             prev = o;
             // ---- posterior of the cell, on the scale 2^-K:  post = prefix * suffix
             const double suf = cur_v[q];
-            const int kap = -(sc.L + cur_L[q]) - K;
+            const int nLK = -(sc.L + K);  // scalar
+            const int kap = nLK - cur_L[q];
             const double post = in_band ? ldexp(o * suf, kap) : 0.0;
             rsum += post;
             // ---- path step (node.cpp:52-91): running maximum of the previous row, strict '>' at the
@@ -483,23 +513,24 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
             // Scores are (double, integer scale): stored = true * 2^scale.  The running maximum is kept
             // normalised (bestn in [0.5,1), scale G); an incoming score is brought onto that scale
             // before comparing (far below -> 0, far above -> inf, both compare correctly).
-            const double dva = ldexp(dv, (bestn == 0.0) ? 0 : G - Gin);
+            const double dva = ldexp(dv, G - Gin);  // no maximum yet: G = GBIG, any dv > 0 becomes +inf
             const bool upd = active && (dva - bestn > bthr);
             if (upd) {
               bestn = __builtin_amdgcn_frexp_mant(dv);         // in [0.5, 1)
               G = Gin - __builtin_amdgcn_frexp_exp(dv);        // its scale; -G = true exponent
               bthr = bestn * ((double)abs(G) * 0x1.0p-52);
             }
-            bits |= upd ? (1u << (u & 31)) : 0u;
+            bits = (bits << 1) | (upd ? 1u : 0u);  // step u ends up at bit 31 - (u & 31)
             double dpv = bestn * post;  // post is already 0 outside the band
             int Gd = G;
             if (init_live) {
               asm volatile("" ::: "memory");
               if (is_init) { dpv = post; Gd = 0; }
             }
-            if (__any(r == top && in_band)) {
+            if (top_live) {
+              asm volatile("" ::: "memory");
               const double da = ldexp(dpv, (fbest == 0.0) ? 0 : fG - Gd);
-              if (r == top && (da - fbest > fthr)) {
+              if (r == top && in_band && (da - fbest > fthr)) {
                 fbest = dpv;
                 fG = Gd;
                 fidx = i;
@@ -509,7 +540,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
             hist2[su * 64 + lane] = make_double2(o, dpv);
             ghist[su * 64 + lane] = Gd;
             if ((u & 31) == 31 || u == n_steps - 1) {
-              bp[(size_t)(u >> 5) * 64 + lane] = bits;
+              bp[(size_t)(u >> 5) * 64 + lane] = bits << (31 - (u & 31));
               bits = 0;
             }
             // refill the prefetch slot just consumed
@@ -572,7 +603,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
         const int pm = g.transitions ? ((r - 1) & 1 ? 0 : MEL) : MEL;
         int u = idx + c * r - t_min;
         int w = u >> 5;
-        uint32_t v = bp[(size_t)w * 64 + (r & 63)] & (0xffffffffu >> (31 - (u & 31)));
+        uint32_t v = bp[(size_t)w * 64 + (r & 63)] & (0xffffffffu << (31 - (u & 31)));
         while (v == 0 && w > 0) {
           --w;
           v = bp[(size_t)w * 64 + (r & 63)];
@@ -582,7 +613,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
           atomicAdd(g.n_retry, 1);
           break;
         }
-        int uu = (w << 5) + (31 - __clz(v));
+        int uu = (w << 5) + (31 - (__ffs(v) - 1));
         idx = uu + t_min - c * r - pm;
       }
       g.out_status[rd] = st;
@@ -595,6 +626,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
 int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadMeta *metas,
                   const RowParam *rows, const PlanTotals &tot, int32_t *out_events,
                   int32_t *out_status, int *n_retry) {
+  static_assert(WS_LANE_F < (int)(sizeof(ctx->ws) / sizeof(ctx->ws[0])), "workspace table too small");
   *n_retry = 0;
   if (a.n_reads == 0) return NVK_OK;
   const int mel = a.mel;
@@ -606,10 +638,12 @@ int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadM
   const int max_steps = tot.max_steps < 1 ? 1 : tot.max_steps;
   const int c = max_c < ALIGN1_C_CAP ? max_c : ALIGN1_C_CAP;  // wider reads go to the exact kernel
   if (c + mel + 1 >= RS) return NVK_ERR_UNSUPPORTED;
-  const int H = c + mel + 1;
+  // history ring: ages 1 .. c+mel are read; the oldest slot is read and then overwritten in the same
+  // step (LDS operations of one wave execute in program order)
+  const int H = c + mel;
   int SR = 256;
   while (SR < 64 * c + CH) SR <<= 1;
-  size_t lds = (size_t)ETN * 8 + (size_t)SR * 8 + (size_t)TABN * sizeof(RowParam) + (size_t)H * 64 * 20 + 16;
+  size_t lds = (size_t)ETN * 8 + (size_t)SR * 8 + (size_t)H * 64 * 20 + 16;
   int per_cu = (int)((160 * 1024) / lds);
   if (per_cu > 16) per_cu = 16;
   if (per_cu < 1) per_cu = 1;
@@ -628,13 +662,19 @@ int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadM
   if (rc) return rc;
   rc = nvk_ws_reserve(ctx, WS_MISC, 256);
   if (rc) return rc;
+  const int64_t rows_total = transitions ? 2 * a.total_ref : a.total_ref + a.n_reads;
+  rc = nvk_ws_reserve(ctx, WS_LANE_F, (size_t)(rows_total + 1) * sizeof(Lane3));
+  if (rc) return rc;
+  rc = nvk_ws_reserve(ctx, WS_LANE_R, (size_t)(rows_total + 1) * sizeof(Lane3));
+  if (rc) return rc;
   int *counter = (int *)ctx->ws[WS_MISC];
   int *d_retry = counter + 2;
   NVK_HIP(hipMemsetAsync(counter, 0, 4 * sizeof(int), ctx->stream));
 
   Align3Args g;
   g.metas = metas;
-  g.rows = rows;
+  g.fwdl = (const Lane3 *)ctx->ws[WS_LANE_F];
+  g.revl = (const Lane3 *)ctx->ws[WS_LANE_R];
   g.signal = a.signal;
   g.spill_v = (double *)ctx->ws[WS_SPILL];
   g.spill_L = (int32_t *)ctx->ws[WS_STAGE];
@@ -660,6 +700,12 @@ int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadM
     case 3: kern = align3_kernel<3>; break;
     default: kern = align3_kernel<4>; break;
   }
+  {
+    TimerScope ts(ctx, NVK_K_PLAN);
+    hipLaunchKernelGGL(lane3_kernel, dim3((unsigned)a.n_reads), dim3(256), 0, ctx->stream, metas, rows,
+                       (Lane3 *)ctx->ws[WS_LANE_F], (Lane3 *)ctx->ws[WS_LANE_R], (int)a.n_reads);
+  }
+  NVK_HIP(hipGetLastError());
   {
     TimerScope ts(ctx, NVK_K_ALIGN);
     hipLaunchKernelGGL(kern, dim3((unsigned)slots), dim3(64), lds, ctx->stream, g);

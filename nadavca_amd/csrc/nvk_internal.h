@@ -85,6 +85,9 @@ struct DeviceModel {
 };
 
 // ----- host-side objects ------------------------------------------------------------------
+enum { WS_META = 0, WS_ROWS = 1, WS_BANDTMP = 2, WS_SPILL = 3, WS_BP = 4, WS_MISC = 5, WS_ROWS2 = 6, WS_STAGE = 7,
+       WS_SPILL_B = 8, WS_STAGE_B = 9, WS_BP_B = 10, WS_LANE_F = 11, WS_LANE_R = 12, WS_COUNT = 13 };
+
 struct nvk_ctx {
   int device;
   hipStream_t stream;
@@ -93,8 +96,8 @@ struct nvk_ctx {
   int slots_override;
   int num_cus;
   // growable workspaces (device)
-  void *ws[12];
-  size_t ws_bytes[12];
+  void *ws[WS_COUNT];
+  size_t ws_bytes[WS_COUNT];
   // timing
   int timing_on;
   double k_ms[NVK_K_COUNT];
@@ -102,6 +105,7 @@ struct nvk_ctx {
   hipEvent_t ev0, ev1;
   // stats of the last batch
   int64_t last_cells, last_steps, last_spill_bytes;
+  int64_t last_retries;  // reads of the last refine batch redone by the exact kernel
 };
 
 struct nvk_model {
@@ -110,8 +114,6 @@ struct nvk_model {
   double *d_mean, *d_ac, *d_mc;
 };
 
-enum { WS_META = 0, WS_ROWS = 1, WS_BANDTMP = 2, WS_SPILL = 3, WS_BP = 4, WS_MISC = 5, WS_ROWS2 = 6, WS_STAGE = 7,
-       WS_SPILL_B = 8, WS_STAGE_B = 9, WS_BP_B = 10, WS_COUNT = 11 };
 
 void nvk_set_error(const char *fmt, ...);
 int nvk_ws_reserve(nvk_ctx *ctx, int which, size_t bytes);
