@@ -31,7 +31,7 @@
 
 namespace {
 
-constexpr int CH = 128;     // signal refill chunk (samples)
+constexpr int CH = 64;      // signal refill chunk (samples)
 constexpr int PF = 4;       // forward sweep: spill prefetch depth (steps)
 constexpr int RS = 16;      // rescale period (steps); must exceed c + mel
 constexpr int GBIG = 1 << 24;  // scale of an empty running maximum (see the path step)
@@ -83,12 +83,12 @@ struct Align3Args {
 
 
 // e(x) * 2^dshift as a plain double.  `ac`/`mc` are the reference's constants
-// (kmer_model.cpp:9-12,48-50) times 256*log2(e), so y = 256 * log2 e(x); constant rows have mc == 0
-// and impossible ones (ac == -inf) are loaded as ac = -2^30, mc = 0, whose 2^(-2^22) flushes to an
-// exact 0.  2^(y/256) = 2^(k) * 2^(j/256) * 2^(g/256), j from a 256-entry LDS table, the last factor
-// a degree-4 Taylor polynomial (|g| <= 1/2: error <= 2.2e-16, i.e. rounding level).  A non-finite
+// (kmer_model.cpp:9-12,48-50) times 128*log2(e), so y = 128 * log2 e(x); constant rows have mc == 0
+// and impossible ones (ac == -inf) are loaded as ac = -2^30, mc = 0, whose 2^(-2^23) flushes to an
+// exact 0.  2^(y/128) = 2^(k) * 2^(j/128) * 2^(g/128), j from a 128-entry LDS table, the last factor
+// a degree-5 Taylor polynomial (|g| <= 1/2: truncation 5e-19, i.e. below rounding level).  A non-finite
 // sample gives NaN, which the caller's range check turns into a retry by the exact kernel.
-constexpr int ETN = 256;
+constexpr int ETN = 128;
 // v_fma_f64 with three VGPR operands: keeps the compiler from choosing v_fmac + a 64-bit register
 // copy of the coefficient per term
 __device__ __forceinline__ double fma_vvv(double a, double b, double c) {
@@ -96,7 +96,7 @@ __device__ __forceinline__ double fma_vvv(double a, double b, double c) {
   asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
   return r;
 }
-#define DENS_SCALE (256.0 * 0x1.71547652b82fep+0)
+#define DENS_SCALE (128.0 * 0x1.71547652b82fep+0)
 __device__ __forceinline__ double density(double x, double mean, double ac, double mc, int dshift,
                                           const double *etab) {
   const double d = x - mean;
@@ -105,11 +105,12 @@ __device__ __forceinline__ double density(double x, double mean, double ac, doub
   const double gq = y - kk;
   const int ki = (int)kk;
   const double tj = etab[ki & (ETN - 1)];
-  double p = fma_vvv(gq, 0x1.3b2ab6fba4e77p-39, 0x1.c6b08d704a0c0p-29);
-  p = fma_vvv(p, gq, 0x1.ebfbdff82c58fp-19);
-  p = fma_vvv(p, gq, 0x1.62e42fefa39efp-9);
+  double p = fma_vvv(gq, 0x1.5d87fe78a6731p-45, 0x1.3b2ab6fba4e77p-35);
+  p = fma_vvv(p, gq, 0x1.c6b08d704a0c0p-26);
+  p = fma_vvv(p, gq, 0x1.ebfbdff82c58fp-17);
+  p = fma_vvv(p, gq, 0x1.62e42fefa39efp-8);
   p = fma(p, gq, 1.0);
-  return ldexp(tj * p, (ki >> 8) + dshift);
+  return ldexp(tj * p, (ki >> 7) + dshift);
 }
 
 __device__ __forceinline__ void set_density_consts(Lane3 &l, const RowParam &o) {
