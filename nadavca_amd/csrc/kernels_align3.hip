@@ -33,7 +33,8 @@ namespace {
 
 constexpr int CH = 64;      // signal refill chunk (samples)
 constexpr int PF = 4;       // forward sweep: spill prefetch depth (steps)
-constexpr int RS = 16;      // rescale period (steps); must exceed c + mel
+constexpr int RSH = 4;
+constexpr int RS = 1 << RSH;  // rescale period (steps); must exceed c + mel
 constexpr int GBIG = 1 << 24;  // scale of an empty running maximum (see the path step)
 constexpr int TARGET = 250; // exponent the largest live value is moved to
 #define HUGE_V 0x1.0p+900
@@ -66,7 +67,7 @@ struct Align3Args {
   const Lane3 *revl;
   const double *signal;
   double *spill_v;   // suffix values, [slot][step][lane], scaled by 2^L(step)
-  int32_t *spill_L;  // [slot][step] running log-scale of the reverse sweep
+  int32_t *spill_L;  // [slot][reverse step / RS] running log-scale of the reverse sweep
   uint32_t *bp;      // path update bits, [slot][step/32][lane]
   int64_t spill_stride;  // cells per slot
   int64_t L_stride;      // ints per slot
@@ -111,6 +112,32 @@ __device__ __forceinline__ double density(double x, double mean, double ac, doub
   p = fma_vvv(p, gq, 0x1.62e42fefa39efp-8);
   p = fma(p, gq, 1.0);
   return ldexp(tj * p, (ki >> 7) + dshift);
+}
+
+// The same in two halves, so that the sample and table reads of the NEXT step's density can be issued
+// at the top of a step and their latency overlaps the cell's own arithmetic.
+struct DensHalf {
+  double tj, p;
+  int ki;
+};
+__device__ __forceinline__ DensHalf density_begin(double x, double mean, double ac, double mc,
+                                                  const double *etab) {
+  DensHalf h;
+  const double d = x - mean;
+  const double y = fma(-(d * d), mc, ac);
+  const double kk = rint(y);
+  const double gq = y - kk;
+  h.ki = (int)kk;
+  h.tj = etab[h.ki & (ETN - 1)];
+  double p = fma_vvv(gq, 0x1.5d87fe78a6731p-45, 0x1.3b2ab6fba4e77p-35);
+  p = fma_vvv(p, gq, 0x1.c6b08d704a0c0p-26);
+  p = fma_vvv(p, gq, 0x1.ebfbdff82c58fp-17);
+  p = fma_vvv(p, gq, 0x1.62e42fefa39efp-8);
+  h.p = fma(p, gq, 1.0);
+  return h;
+}
+__device__ __forceinline__ double density_end(const DensHalf &h, int dshift) {
+  return ldexp(h.tj * h.p, (h.ki >> 7) + dshift);
 }
 
 __device__ __forceinline__ void set_density_consts(Lane3 &l, const RowParam &o) {
@@ -296,12 +323,15 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
               TAKE_LANE(nx);
               hi = nx.end;
               is_init = false;
-              if (r >= 64) nx = revl[r - 64];
               e = density(ring[i & RM], mean, ac2, mc2, (sc.u_last == u) ? sc.d_last : 0, etab);
             } else {
               hi = -0x40000000; bs = -0x40000000;
             }
           }
+          // Every lane (re)fetches its next row here, not only the lanes that switched: a load under
+          // a divergent branch is copied into the loop-carried registers right away, which would
+          // expose its full latency at every switch.
+          nx = revl[max(r - 64, 0)];
           while (r_old >= 0 && __builtin_amdgcn_readlane(r, r_old & 63) != r_old) r_old--;
           init_live = init_live && (__builtin_amdgcn_readlane(r, top & 63) == top);
         }
@@ -317,27 +347,30 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
             __syncthreads();
           }
         }
+        // LDS reads first: the neighbour's value and the sample of the next step's density
+        const int hs = (melr == 0 ? sB : sA) * 64 + ((lane + 1) & 63);
+        const double xn = ring[(i - 1) & RM];
+        double pv = hist[hs];
         // scalar shifts that bring a neighbour value from D steps ago to the current scale
         const int age = u - sc.u_last;
         const int shT = (age < c) ? sc.d_last : 0;                       // D = c      (mel 0 rows)
         const int shE = (age >= MEL && age < c + MEL) ? sc.d_last : 0;  // D = c+MEL  (beyond the densities' own shifts)
+        const DensHalf dn = density_begin(xn, mean, ac2, mc2, etab);
         // ---- the cell (r, i): out = P * pred[i + mel] + e(s[i]) * out[i + 1]
         const bool active = (i <= hi) && (i >= bs);
         double P = emission_product<MEL>(e, e1, e2, e3);
         P = (melr == 0) ? 1.0 : P;
         const int j = i + melr;
-        const int hs = (melr == 0 ? sB : sA) * 64 + ((lane + 1) & 63);
-        double pv = hist[hs];
         pv = (j >= pbs && j <= pbe) ? pv : 0.0;
         double t1 = P * pv;
         if ((shT | shE) != 0) {  // uniform and rare: keep it a branch
-          asm volatile("" ::: "memory");
+          asm volatile("");
           t1 = ldexp(t1, melr == 0 ? shT : shE);
         }
         double o = fma(e, prev, t1);
         o = active ? o : 0.0;
         if (init_live) {
-          asm volatile("" ::: "memory");
+          asm volatile("");
           if (is_init) o = active ? ldexp(1.0, sc.L) : 0.0;
         }
         // Cells far off the likely path are thousands of bits below the wave's largest value and
@@ -346,12 +379,14 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
         suspect |= !(o <= HUGE_V);
         prev = o;
         if (__builtin_amdgcn_readfirstlane(r) == 0) {  // row 0 lives on lane 0; only its kmax is read
-          asm volatile("" ::: "memory");
+          asm volatile("");
           if (o != 0.0) kmax = max(kmax, __builtin_amdgcn_frexp_exp(o) - sc.L);
         }
         hist[su * 64 + lane] = o;
         spill_v[(size_t)(t - t_min) * 64 + lane] = o;
-        if (lane == 0) spill_L[t - t_min] = sc.L;
+        if ((u & (RS - 1)) == 0) {  // the scale only moves on these steps
+          if (lane == 0) spill_L[u >> RSH] = sc.L;
+        }
         // ---- rescale decision for the next step, then the next step's density
         if (((u + 1) % RS) == 0) {
           int ex = (o != 0.0) ? __builtin_amdgcn_frexp_exp(o) : -0x40000000;
@@ -360,7 +395,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
         }
         i -= 1;
         e3 = e2; e2 = e1; e1 = e;
-        e = density(ring[i & RM], mean, ac2, mc2, sc.d_next, etab);
+        e = density_end(dn, sc.d_next);
         su = (su + 1 == H) ? 0 : su + 1;
         sA = (sA + 1 == H) ? 0 : sA + 1;
         sB = (sB + 1 == H) ? 0 : sB + 1;
@@ -369,7 +404,8 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
       K = __builtin_amdgcn_readfirstlane(kmax);
       if (K == -0x40000000) K = 0;
     }
-    __syncthreads();
+    __syncthreads();  // (also drains the stores)
+    __builtin_amdgcn_s_dcache_inv();
 
     // ================= forward sweep: prefix rows, posterior, path DP, update bits =================
     double fbest = 0.0, fthr = 0.0;
@@ -419,12 +455,14 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
       bool top_live = (top < 64); // (uniform) the last row has been started
 
       double cur_v[PF];
-      int cur_L[PF];
 #pragma unroll
-      for (int q = 0; q < PF; q++) {
-        cur_v[q] = spill_v[(size_t)q * 64 + lane];
-        cur_L[q] = spill_L[q];
-      }
+      for (int q = 0; q < PF; q++) cur_v[q] = spill_v[(size_t)q * 64 + lane];
+      // The reverse sweep's scale, one value per RS steps, comes through the scalar cache: it is
+      // uniform, and a vector load per step would put one more operation on the wait counter that
+      // guards the spill prefetch.  The cache was invalidated after the reverse sweep's stores.
+      const __attribute__((address_space(4))) int32_t *sL =
+          (const __attribute__((address_space(4))) int32_t *)(uintptr_t)spill_L;
+      int Lrev = 0;
 
       for (int ub = 0; ub < n_steps; ub += PF) {
 #pragma unroll
@@ -452,12 +490,12 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
                   TAKE_LANE(nx);
                   be = nx.end; lo = nx.lo;
                   is_init = false;
-                  if (r + 64 < T) nx = fwdl[r + 64];
                   e = density(ring[(i - 1) & RM], mean, ac2, mc2, (sc.u_last == u) ? sc.d_last : 0, etab);
                 } else {
                   lo = 0x40000000; be = 0x40000000;
                 }
               }
+              nx = fwdl[min(r + 64, top)];  // all lanes, see the reverse sweep
               while (r_old < T && __builtin_amdgcn_readlane(r, r_old & 63) != r_old) r_old++;
               init_live = init_live && (__builtin_amdgcn_readfirstlane(r) == 0);
               top_live = (__builtin_amdgcn_readlane(r, top & 63) == top);
@@ -474,9 +512,15 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
                 __syncthreads();
               }
             }
+            // LDS reads first: the neighbour's values and the sample of the next step's density
+            const int hs = (melr == 0 ? sB : sA) * 64 + ((lane - 1) & 63);
+            const double xn = ring[i & RM];
+            const double2 hv = hist2[hs];
+            const int Gin = ghist[hs];
             const int age = u - sc.u_last;
             const int shT = (age < c) ? sc.d_last : 0;
             const int shE = (age >= MEL && age < c + MEL) ? sc.d_last : 0;
+            const DensHalf dn = density_begin(xn, mean, ac2, mc2, etab);
             // ---- the cell (r, i): out = P * pred[i - mel] + e(s[i-1]) * out[i - 1]
             const bool active = (i >= lo) && (i <= be);
             const bool in_band = active && (i >= bs);
@@ -484,29 +528,27 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
             P = (melr == 0) ? 1.0 : P;
             const int j = i - melr;
             const bool ok = (j >= pbs) && (j <= pbe);
-            const int hs = (melr == 0 ? sB : sA) * 64 + ((lane - 1) & 63);
-            const double2 hv = hist2[hs];
             double pv = hv.x, dv = hv.y;
-            const int Gin = ghist[hs];
             pv = ok ? pv : 0.0;
             dv = ok ? dv : 0.0;
             double t1 = P * pv;
             if ((shT | shE) != 0) {  // uniform and rare: keep it a branch
-              asm volatile("" ::: "memory");
+              asm volatile("");
               t1 = ldexp(t1, melr == 0 ? shT : shE);
             }
             double o = fma(e, prev, t1);
             o = active ? o : 0.0;
             if (init_live) {
-              asm volatile("" ::: "memory");
+              asm volatile("");
               if (is_init) o = in_band ? ldexp(1.0, sc.L) : 0.0;
             }
             suspect |= !(o <= HUGE_V);
             prev = o;
             // ---- posterior of the cell, on the scale 2^-K:  post = prefix * suffix
             const double suf = cur_v[q];
-            const int nLK = -(sc.L + K);  // scalar
-            const int kap = nLK - cur_L[q];
+            const int ur = n_steps - 1 - u;  // the reverse sweep's step for this anti-diagonal
+            if ((ur & (RS - 1)) == RS - 1 || u == 0) Lrev = sL[ur >> RSH];
+            const int kap = -(sc.L + K) - Lrev;  // scalar
             const double post = in_band ? ldexp(o * suf, kap) : 0.0;
             rsum += post;
             // ---- path step (node.cpp:52-91): running maximum of the previous row, strict '>' at the
@@ -525,11 +567,11 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
             double dpv = bestn * post;  // post is already 0 outside the band
             int Gd = G;
             if (init_live) {
-              asm volatile("" ::: "memory");
+              asm volatile("");
               if (is_init) { dpv = post; Gd = 0; }
             }
             if (top_live) {
-              asm volatile("" ::: "memory");
+              asm volatile("");
               const double da = ldexp(dpv, (fbest == 0.0) ? 0 : fG - Gd);
               if (r == top && in_band && (da - fbest > fthr)) {
                 fbest = dpv;
@@ -546,7 +588,6 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
             }
             // refill the prefetch slot just consumed
             cur_v[q] = spill_v[(size_t)(u + PF) * 64 + lane];
-            cur_L[q] = spill_L[u + PF];
             // ---- rescale decision for the next step, then the next step's density
             if (((u + 1) % RS) == 0) {
               int ex = (o != 0.0) ? __builtin_amdgcn_frexp_exp(o) : -0x40000000;
@@ -555,7 +596,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
             }
             i += 1;
             e3 = e2; e2 = e1; e1 = e;
-            e = density(ring[(i - 1) & RM], mean, ac2, mc2, sc.d_next, etab);
+            e = density_end(dn, sc.d_next);
             su = (su + 1 == H) ? 0 : su + 1;
             sA = (sA + 1 == H) ? 0 : sA + 1;
             sB = (sB + 1 == H) ? 0 : sB + 1;
@@ -651,7 +692,7 @@ int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadM
   int64_t slots = ctx->slots_override > 0 ? ctx->slots_override : (int64_t)ctx->num_cus * per_cu;
   if (slots > a.n_reads) slots = a.n_reads;
   const int64_t spill_stride = ((int64_t)max_steps + 2 * PF) * 64;
-  const int64_t L_stride = (int64_t)max_steps + 2 * PF + 2;
+  const int64_t L_stride = (int64_t)(max_steps >> RSH) + 4;
   const int64_t bp_stride = (int64_t)((max_steps + 31) / 32 + 1) * 64;
   const int64_t cap = (int64_t)48 << 30;
   while (slots > 1 && slots * spill_stride * 8 > cap) slots /= 2;
@@ -715,6 +756,6 @@ int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadM
   NVK_HIP(hipMemcpyAsync(n_retry, d_retry, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   NVK_HIP(hipStreamSynchronize(ctx->stream));
   // bytes the sweeps stream through HBM: 8 B written + 8 B read per (step, lane) + scales + bits
-  ctx->last_spill_bytes = (int64_t)tot.steps * 64 * 16 + (int64_t)tot.steps * 8 + (int64_t)tot.steps * 8 * 2;
+  ctx->last_spill_bytes = (int64_t)tot.steps * 64 * 16 + (int64_t)tot.steps / RS * 8 + (int64_t)tot.steps * 8 * 2;
   return NVK_OK;
 }
