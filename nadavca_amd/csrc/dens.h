@@ -1,0 +1,81 @@
+// Table-based Gaussian density for the plain-double kernels (kernels_align3.hip, kernels_ell.hip).
+#pragma once
+#include <math.h>
+
+namespace dens {
+
+// e(x) * 2^dshift as a plain double.  `ac`/`mc` are the reference's constants
+// (kmer_model.cpp:9-12,48-50) times 128*log2(e), so y = 128 * log2 e(x); constant rows have mc == 0
+// and impossible ones (ac == -inf) are loaded as ac = -2^30, mc = 0, whose 2^(-2^23) flushes to an
+// exact 0.  2^(y/128) = 2^(k) * 2^(j/128) * 2^(g/128), j from a 128-entry LDS table, the last factor
+// a degree-5 Taylor polynomial (|g| <= 1/2: truncation 5e-19, i.e. below rounding level).  A non-finite
+// sample gives NaN, which the caller's range check turns into a retry by the exact kernel.
+constexpr int ETN = 128;  // table entries: 2^(j/128)
+// v_fma_f64 with three VGPR operands: keeps the compiler from choosing v_fmac + a 64-bit register
+// copy of the coefficient per term
+__device__ __forceinline__ double fma_vvv(double a, double b, double c) {
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+#define DENS_SCALE (128.0 * 0x1.71547652b82fep+0)
+__device__ __forceinline__ double density(double x, double mean, double ac, double mc, int dshift,
+                                          const double *etab) {
+  const double d = x - mean;
+  const double y = fma(-(d * d), mc, ac);
+  const double kk = rint(y);
+  const double gq = y - kk;
+  const int ki = (int)kk;
+  const double tj = etab[ki & (ETN - 1)];
+  double p = fma_vvv(gq, 0x1.5d87fe78a6731p-45, 0x1.3b2ab6fba4e77p-35);
+  p = fma_vvv(p, gq, 0x1.c6b08d704a0c0p-26);
+  p = fma_vvv(p, gq, 0x1.ebfbdff82c58fp-17);
+  p = fma_vvv(p, gq, 0x1.62e42fefa39efp-8);
+  p = fma(p, gq, 1.0);
+  return ldexp(tj * p, (ki >> 7) + dshift);
+}
+
+// The same in two halves, so that the sample and table reads of the NEXT step's density can be issued
+// at the top of a step and their latency overlaps the cell's own arithmetic.
+struct DensHalf {
+  double tj, p;
+  int ki;
+};
+__device__ __forceinline__ DensHalf density_begin(double x, double mean, double ac, double mc,
+                                                  const double *etab) {
+  DensHalf h;
+  const double d = x - mean;
+  const double y = fma(-(d * d), mc, ac);
+  const double kk = rint(y);
+  const double gq = y - kk;
+  h.ki = (int)kk;
+  h.tj = etab[h.ki & (ETN - 1)];
+  double p = fma_vvv(gq, 0x1.5d87fe78a6731p-45, 0x1.3b2ab6fba4e77p-35);
+  p = fma_vvv(p, gq, 0x1.c6b08d704a0c0p-26);
+  p = fma_vvv(p, gq, 0x1.ebfbdff82c58fp-17);
+  p = fma_vvv(p, gq, 0x1.62e42fefa39efp-8);
+  h.p = fma(p, gq, 1.0);
+  return h;
+}
+__device__ __forceinline__ double density_end(const DensHalf &h, int dshift) {
+  return ldexp(h.tj * h.p, (h.ki >> 7) + dshift);
+}
+
+
+// the table itself: 1 KB of LDS per block, filled once per kernel
+__device__ __forceinline__ void fill_table(double *etab, int lane, int nthreads) {
+  for (int q = lane; q < ETN; q += nthreads) etab[q] = exp2((double)q * (1.0 / ETN));
+}
+
+// row constants as density() wants them: the reference's ac/mc (kmer_model.cpp:9-12) times
+// 128*log2(e); an impossible row (ac == -inf) becomes a constant that flushes to exactly 0
+__device__ __forceinline__ void scale_consts(double ac_in, double mc_in, double &ac, double &mc) {
+  ac = ac_in * DENS_SCALE;
+  mc = mc_in * DENS_SCALE;
+  if (!(ac > -0x1.0p+900)) {
+    ac = -0x1.0p+30;
+    mc = 0.0;
+  }
+}
+
+}  // namespace dens

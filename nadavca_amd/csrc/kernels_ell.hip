@@ -22,12 +22,28 @@
 // positions plus one closing lane that applies the last wobble row and accumulates
 // sum_x cur[x] * suffix[last+1][x].
 //
+// Phase C has two implementations of the same recurrences.  Wrong-base hypotheses routinely couple
+// quantities that are thousands of bits apart (a k-mer 40 sigma off costs ~1000 bits per sample), so
+// every value keeps its own exponent in both; plain doubles under a shared scale were tried and lose
+// exactly the terms that decide such hypotheses.  The default (FAST) variant makes the scaled numbers
+// cheap instead:
+//   * sums are not re-normalised (xm-style frexp) on every operation: add_lazy aligns the two
+//     mantissas and adds, the state is normalised once every 16 steps;
+//   * ONE table-based density per lane (dens.h) delivered directly as (mantissa, exponent); the
+//     mixture's other component and the predecessor value come from the neighbouring lane with DPP row
+//     shifts (lane rho at step u works on the cell lane rho-1 worked on at step u-1) — no LDS traffic;
+//   * the three input streams are prefetched in place (no double-buffer copies).
+// The exact variant (NADAVCA_ELL_KERNEL=1, and k-mers longer than 6) is the original formulation with
+// two polynomial densities per lane and LDS hand-over; both agree to ~1e-15 relative
+// (tools/dbg_ell.py, tests/test_gpu_ell.py).
+//
 // Quirks kept on purpose: the mixture is (g1 + g2) * exp(-2), not / 2; the
 // closing wobble row of a hypothesis lives on band row `last`, not `last + 1`.
 #include <math.h>
 
 #include "nvk_internal.h"
 #include "xmath.h"
+#include "dens.h"
 
 namespace {
 
@@ -36,7 +52,9 @@ using xm::X;
 constexpr int CH = 128;    // signal refill chunk (samples)
 constexpr int TABN = 128;  // descriptor window (two 64-position blocks)
 constexpr int PF = 4;      // phase C prefetch depth (steps)
-constexpr int GL = 8;      // lanes per hypothesis group (k + 1 <= GL)
+constexpr int GL = 8;      // lanes per hypothesis group (exact: k + 1 <= GL; fast: k + 2 <= GL)
+constexpr int HRS = 16;    // fast phase C: steps between mantissa normalisations
+#define EXPM2_D 0x1.152aaa3bf81ccp-3  // exp(-2), see expm2()
 
 #define WAVE_SYNC()                                        \
   do {                                                     \
@@ -59,6 +77,67 @@ struct EllArgs {
   double *out_ll;
   int32_t *out_status;
 };
+
+// ---- fast phase C ----------------------------------------------------------------------------
+template <int MEL>
+struct LaneState;
+struct HypDesc {
+  double bm, bac, bmc;  // the lane's own density, constants scaled for dens::density
+  int wbs, wbe, ebe, pbs, pbe, has_wob;
+};
+
+// a + b without re-normalising the mantissa (it drifts by a few bits per step at most; the caller
+// normalises every HRS steps).  Zeros carry the exponent XZ, so the other operand passes unchanged.
+__device__ __forceinline__ X add_lazy(X a, X b) {
+  const int e = max(a.e, b.e);
+  return X{ldexp(a.m, a.e - e) + ldexp(b.m, b.e - e), e};
+}
+
+// e(x) as (mantissa in [1,2), exponent): dens::density without its final ldexp
+__device__ __forceinline__ X density_x(double x, double mean, double ac, double mc, const double *etab) {
+  const dens::DensHalf h = dens::density_begin(x, mean, ac, mc, etab);
+  return X{h.tj * h.p, h.ki >> 7};
+}
+
+// fused_step with lazy sums; gb/ga are the two mixture components at this cell's sample
+template <int MEL>
+__device__ __forceinline__ X fused_step_fast(const HypDesc &d, LaneState<MEL> &st, int i, X gb, X ga,
+                                             X pred, bool on) {
+  X mix = add_lazy(ga, gb);
+  mix.m *= EXPM2_D;
+  X wn = add_lazy(pred, xm::mul(mix, st.wq[0]));  // node_next_row.h with mel = 0
+  wn = xm::sel(d.has_wob != 0, wn, pred);
+  wn = xm::sel(on && i >= d.wbs && i <= d.wbe, wn, xm::zero());
+#pragma unroll
+  for (int k = MEL; k >= 1; k--) st.wq[k] = st.wq[k - 1];
+  st.wq[0] = wn;
+  X P = xm::one();
+  if (MEL >= 1) {
+    P = gb;
+#pragma unroll
+    for (int k = 0; k < MEL - 1; k++) P = xm::mul(P, st.gh[k]);
+  }
+  X en = add_lazy(xm::mul(P, st.wq[MEL]), xm::mul(gb, st.em));
+  en = xm::sel(on && i >= MEL && i <= d.ebe, en, xm::zero());
+  st.em = en;
+  if (MEL >= 2) {
+#pragma unroll
+    for (int k = MEL - 2; k >= 1; k--) st.gh[k] = st.gh[k - 1];
+    st.gh[0] = gb;
+  }
+  return en;
+}
+
+// value of the previous lane (DPP row_shr:1; the first lane of each 16-lane row reads 0)
+__device__ __forceinline__ double dpp_shr1(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x111, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x111, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ X dpp_shr1(X v) {
+  return X{dpp_shr1(v.m), __builtin_amdgcn_update_dpp(xm::XZ, v.e, 0x111, 0xf, 0xf, false)};
+}
 
 __device__ __forceinline__ X density(double x, double mean, double ac2, double mc2) {
   double d = x - mean;
@@ -239,10 +318,11 @@ __device__ void sweep(const FusedParam *desc, int R, int N, int c, const double 
   }
 }
 
-template <int MEL>
+template <int MEL, bool FAST>
 __global__ __launch_bounds__(64, 3) void ell_kernel(EllArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  double *ring = reinterpret_cast<double *>(smem);
+  double *etab = reinterpret_cast<double *>(smem);
+  double *ring = etab + dens::ETN;
   FusedParam *tab = reinterpret_cast<FusedParam *>(ring + g.SR);
   double *hist_m = reinterpret_cast<double *>(tab + TABN);
   int *hist_e = reinterpret_cast<int *>(hist_m + (size_t)g.H * 64);
@@ -257,6 +337,7 @@ __global__ __launch_bounds__(64, 3) void ell_kernel(EllArgs g) {
   double *suf_m = pre_m + g.half;
   int32_t *suf_e = pre_e + g.half;
   for (int q = lane; q < g.SR; q += 64) ring[q] = 0.0;
+  dens::fill_table(etab, lane, 64);
 
   while (true) {
     __syncthreads();
@@ -318,6 +399,118 @@ __global__ __launch_bounds__(64, 3) void ell_kernel(EllArgs g) {
     const int back = dm.k - dm.central - 1, fwd = dm.central;
     const int n_items = R * (alpha - 1);
     const int grp = lane / GL, gl = lane % GL;
+    if (FAST) {
+      // lane roles in a group: 0 = density of the k-mer before `first` (only feeds the mixture of the
+      // first position), 1..npos = the positions first..last, npos+1 = the closing lane.
+      // Lane role rho is at cell i = base + u - rho at step u, so whatever lane rho-1 produced at step
+      // u-1 (emitting value, density) belongs to the cell lane rho works on at step u.
+      const int smax = (int)g.half - 1;
+      for (int b0 = 0; b0 < n_items; b0 += 64 / GL) {
+        const int item = b0 + grp;
+        const bool valid = item < n_items;
+        int p = 0, b = 0, first = 0, last = 0, npos = 0;
+        if (valid) {
+          p = item / (alpha - 1);
+          int bi = item % (alpha - 1);
+          b = bi + (bi >= ref[p] ? 1 : 0);
+          first = max(0, p - back);
+          last = min(R - 1, p + fwd);
+          npos = last - first + 1;
+        }
+        const bool is_pos = valid && gl >= 1 && gl <= npos;
+        const bool is_fin = valid && gl == npos + 1;
+        const bool is_in = valid && gl == 1;  // the lane fed by prefix[first]
+        HypDesc d;
+        d.wbs = 0x40000000; d.wbe = -0x40000000; d.ebe = -0x40000000; d.pbs = 0; d.pbe = -1;
+        d.has_wob = 0; d.bm = 0.0; d.bac = 0.0; d.bmc = 0.0;
+        const double *sm = pre_m;
+        const int32_t *se = pre_e;
+        int sbase = 0, slo = 0x40000000, shi = -0x40000000;
+        int64_t idb = -1;
+        if (valid && gl == 0) {
+          if (first > 0 && g.wobbling) idb = kmer_id_mod(dm, ref, R, cb, nb, ca, na, first - 1, p, b);
+        } else if (is_pos) {
+          const int j = first + gl - 1;
+          idb = kmer_id_mod(dm, ref, R, cb, nb, ca, na, j, p, b);
+          d.has_wob = (j > 0 && g.wobbling) ? 1 : 0;
+          d.wbs = bs[j]; d.wbe = be[j]; d.ebe = be[j + 1];
+          d.pbs = d.wbs; d.pbe = d.wbe;
+          if (is_in) {
+            sbase = rowoff[first] - bs[first];
+            slo = bs[first]; shi = be[first];
+          }
+        } else if (is_fin) {
+          // closing lane: optional wobble row on band `last` (quirk), predecessor = emitting row of
+          // position `last` on band last+1; then the running total against suffix[last+1]
+          d.has_wob = (last + 1 < R && g.wobbling) ? 1 : 0;
+          if (d.has_wob) {
+            idb = kmer_id_mod(dm, ref, R, cb, nb, ca, na, last + 1, p, b);
+            d.wbs = bs[last]; d.wbe = be[last];
+          } else {
+            d.wbs = bs[last + 1]; d.wbe = be[last + 1];
+          }
+          d.pbs = bs[last + 1]; d.pbe = be[last + 1];
+          d.ebe = d.wbe;
+          sm = suf_m; se = suf_e;
+          sbase = rowoff[last + 1] - bs[last + 1];
+          slo = bs[last + 1]; shi = be[last + 1];
+        }
+        if (idb >= 0) {
+          d.bm = dm.mean[idb];
+          dens::scale_consts(dm.ac[idb], dm.mc[idb], d.bac, d.bmc);
+        }
+        const int base = valid ? bs[first] : 0;
+        int steps = 0;
+        if (is_fin) steps = d.wbe - base + gl + 1;
+        for (int dlt = 32; dlt >= 1; dlt >>= 1) steps = max(steps, __shfl_xor(steps, dlt, 64));
+        const int i0 = base - gl;
+        auto sidx = [&](int i) { return min(max(sbase + i, 0), smax); };
+        auto xidx = [&](int i) { return min(max(i - 1, 0), N - 1); };
+        LaneState<MEL> st;
+        st.reset();
+        X acc = xm::zero(), gb_last = xm::one();
+        double cx[PF], cm[PF];
+        int ce[PF];
+#pragma unroll
+        for (int q = 0; q < PF; q++) {
+          cx[q] = sig[xidx(i0 + q)];
+          cm[q] = sm[sidx(i0 + q)];
+          ce[q] = se[sidx(i0 + q)];
+        }
+        for (int ub = 0; ub < steps; ub += PF) {
+#pragma unroll
+          for (int q = 0; q < PF; q++) {
+            const int u = ub + q;
+            if (u < steps) {
+              const int i = i0 + u;
+              if ((u & (HRS - 1)) == HRS - 1) {  // keep the lazily summed mantissas near 1
+                asm volatile("");
+#pragma unroll
+                for (int k = 0; k <= MEL; k++) st.wq[k] = xm::norm(st.wq[k]);
+                st.em = xm::norm(st.em);
+                acc = xm::norm(acc);
+              }
+              X sv{cm[q], ce[q]};
+              sv = xm::sel(i >= slo && i <= shi, sv, xm::zero());
+              const X ga = dpp_shr1(gb_last);
+              X pred = dpp_shr1(st.em);  // emitting row of the lane to the left, one step ago
+              if (is_in) pred = sv;      // prefix[first] (already masked to its band)
+              pred = xm::sel(i >= d.pbs && i <= d.pbe, pred, xm::zero());
+              const bool on = (is_pos || is_fin) && i >= d.wbs && i <= d.ebe;
+              const X gb = density_x(cx[q], d.bm, d.bac, d.bmc, etab);
+              (void)fused_step_fast<MEL>(d, st, i, gb, ga, pred, on);
+              gb_last = gb;
+              const X nacc = add_lazy(acc, xm::mul(st.wq[0], sv));  // node.cpp:31-37
+              acc = xm::sel(is_fin, nacc, acc);
+              cx[q] = sig[xidx(i0 + u + PF)];
+              cm[q] = sm[sidx(i0 + u + PF)];
+              ce[q] = se[sidx(i0 + u + PF)];
+            }
+          }
+        }
+        if (is_fin) out[(size_t)p * alpha + b] = xm::to_log(xm::norm(acc));
+      }
+    } else {
     for (int b0 = 0; b0 < n_items; b0 += 64 / GL) {
       const int item = b0 + grp;
       const bool valid = item < n_items;
@@ -433,6 +626,7 @@ __global__ __launch_bounds__(64, 3) void ell_kernel(EllArgs g) {
       }
       if (is_fin) out[(size_t)p * alpha + b] = xm::to_log(acc);
     }
+    }
     // a read without any valid path has likelihood zero everywhere (the reference returns an
     // all -inf matrix, which its estimator then turns into NaN): report it per read instead
     if (lane == 0) g.out_status[rd] = (no_snp == -INFINITY) ? NVK_READ_NO_PATH : NVK_READ_OK;
@@ -458,7 +652,7 @@ int launch_ell(nvk_ctx *ctx, const DeviceModel &dm, const BatchArgs &a, int wobb
   if (H < 2) H = 2;
   int SR = 256;
   while (SR < 64 * c + CH) SR <<= 1;
-  size_t lds = (size_t)SR * 8 + (size_t)TABN * sizeof(FusedParam) + (size_t)H * 64 * 12 + 16;
+  size_t lds = (size_t)dens::ETN * 8 + (size_t)SR * 8 + (size_t)TABN * sizeof(FusedParam) + (size_t)H * 64 * 12 + 16;
   if (lds > 160 * 1024) {
     nvk_set_error("band too wide for one wave per read: skew %d needs %zu bytes of LDS", c, lds);
     return NVK_ERR_UNSUPPORTED;
@@ -480,6 +674,10 @@ int launch_ell(nvk_ctx *ctx, const DeviceModel &dm, const BatchArgs &a, int wobb
   if (rc) return rc;
   int *counter = (int *)ctx->ws[WS_MISC];
   NVK_HIP(hipMemsetAsync(counter, 0, sizeof(int), ctx->stream));
+  // default: the fast hypothesis phase; NADAVCA_ELL_KERNEL=1 (or a k-mer too long for its lane
+  // layout) selects the original formulation
+  const char *force = getenv("NADAVCA_ELL_KERNEL");
+  const bool fast = !(force && force[0] == '1') && dm.k + 2 <= GL;
 
   EllArgs g;
   g.dm = dm;
@@ -498,19 +696,22 @@ int launch_ell(nvk_ctx *ctx, const DeviceModel &dm, const BatchArgs &a, int wobb
   g.out_status = out_status;
   ctx->last_spill_bytes = (int64_t)tot.cells * 24 * 2;
 
-  void (*kern)(EllArgs) = nullptr;
+  void (*kern_fast)(EllArgs) = nullptr;
+  void (*kern_exact)(EllArgs) = nullptr;
   switch (mel) {
-    case 0: kern = ell_kernel<0>; break;
-    case 1: kern = ell_kernel<1>; break;
-    case 2: kern = ell_kernel<2>; break;
-    case 3: kern = ell_kernel<3>; break;
-    default: kern = ell_kernel<4>; break;
+    case 0: kern_fast = ell_kernel<0, true>; kern_exact = ell_kernel<0, false>; break;
+    case 1: kern_fast = ell_kernel<1, true>; kern_exact = ell_kernel<1, false>; break;
+    case 2: kern_fast = ell_kernel<2, true>; kern_exact = ell_kernel<2, false>; break;
+    case 3: kern_fast = ell_kernel<3, true>; kern_exact = ell_kernel<3, false>; break;
+    default: kern_fast = ell_kernel<4, true>; kern_exact = ell_kernel<4, false>; break;
   }
-  if (lds > 64 * 1024)
-    NVK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (lds > 64 * 1024) {
+    NVK_HIP(hipFuncSetAttribute((const void *)kern_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    NVK_HIP(hipFuncSetAttribute((const void *)kern_exact, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
   {
     TimerScope ts(ctx, NVK_K_ELL_HYP);
-    hipLaunchKernelGGL(kern, dim3((unsigned)slots), dim3(64), lds, ctx->stream, g);
+    hipLaunchKernelGGL(fast ? kern_fast : kern_exact, dim3((unsigned)slots), dim3(64), lds, ctx->stream, g);
   }
   NVK_HIP(hipGetLastError());
   return NVK_OK;
