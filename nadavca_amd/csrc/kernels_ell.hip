@@ -128,15 +128,16 @@ __device__ __forceinline__ X fused_step_fast(const HypDesc &d, LaneState<MEL> &s
   return en;
 }
 
-// value of the previous lane (DPP row_shr:1; the first lane of each 16-lane row reads 0)
+// value of the previous lane (DPP row_shr:1 with bound_ctrl: the first lane of each 16-lane row
+// reads 0 — those lanes are role 0 of a group and never use what arrives from the left)
 __device__ __forceinline__ double dpp_shr1(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(0, lo, 0x111, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(0, hi, 0x111, 0xf, 0xf, false);
+  lo = __builtin_amdgcn_mov_dpp(lo, 0x111, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, 0x111, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ X dpp_shr1(X v) {
-  return X{dpp_shr1(v.m), __builtin_amdgcn_update_dpp(xm::XZ, v.e, 0x111, 0xf, 0xf, false)};
+  return X{dpp_shr1(v.m), __builtin_amdgcn_mov_dpp(v.e, 0x111, 0xf, 0xf, true)};
 }
 
 __device__ __forceinline__ X density(double x, double mean, double ac2, double mc2) {
@@ -404,7 +405,7 @@ __global__ __launch_bounds__(64, 3) void ell_kernel(EllArgs g) {
       // first position), 1..npos = the positions first..last, npos+1 = the closing lane.
       // Lane role rho is at cell i = base + u - rho at step u, so whatever lane rho-1 produced at step
       // u-1 (emitting value, density) belongs to the cell lane rho works on at step u.
-      const int smax = (int)g.half - 1;
+      const int smax = 2 * (int)g.half - 1;
       for (int b0 = 0; b0 < n_items; b0 += 64 / GL) {
         const int item = b0 + grp;
         const bool valid = item < n_items;
@@ -423,8 +424,8 @@ __global__ __launch_bounds__(64, 3) void ell_kernel(EllArgs g) {
         HypDesc d;
         d.wbs = 0x40000000; d.wbe = -0x40000000; d.ebe = -0x40000000; d.pbs = 0; d.pbe = -1;
         d.has_wob = 0; d.bm = 0.0; d.bac = 0.0; d.bmc = 0.0;
-        const double *sm = pre_m;
-        const int32_t *se = pre_e;
+        // input stream of the lane: cell i lives at pre_m/pre_e[sbase + i] (the suffix rows follow the
+        // prefix rows in the same store, g.half cells on), valid for i in [slo, shi]
         int sbase = 0, slo = 0x40000000, shi = -0x40000000;
         int64_t idb = -1;
         if (valid && gl == 0) {
@@ -451,8 +452,7 @@ __global__ __launch_bounds__(64, 3) void ell_kernel(EllArgs g) {
           }
           d.pbs = bs[last + 1]; d.pbe = be[last + 1];
           d.ebe = d.wbe;
-          sm = suf_m; se = suf_e;
-          sbase = rowoff[last + 1] - bs[last + 1];
+          sbase = (int)g.half + rowoff[last + 1] - bs[last + 1];
           slo = bs[last + 1]; shi = be[last + 1];
         }
         if (idb >= 0) {
@@ -463,9 +463,11 @@ __global__ __launch_bounds__(64, 3) void ell_kernel(EllArgs g) {
         int steps = 0;
         if (is_fin) steps = d.wbe - base + gl + 1;
         for (int dlt = 32; dlt >= 1; dlt >>= 1) steps = max(steps, __shfl_xor(steps, dlt, 64));
+        steps = __builtin_amdgcn_readfirstlane(steps);  // uniform trip count
         const int i0 = base - gl;
-        auto sidx = [&](int i) { return min(max(sbase + i, 0), smax); };
-        auto xidx = [&](int i) { return min(max(i - 1, 0), N - 1); };
+        // clamped, unsigned element offsets from uniform base pointers (scalar base + 32-bit offset)
+        auto sidx = [&](int i) { return (unsigned)min(max(sbase + i, 0), smax); };
+        auto xidx = [&](int i) { return (unsigned)min(max(i - 1, 0), N - 1); };
         LaneState<MEL> st;
         st.reset();
         X acc = xm::zero(), gb_last = xm::one();
@@ -474,8 +476,8 @@ __global__ __launch_bounds__(64, 3) void ell_kernel(EllArgs g) {
 #pragma unroll
         for (int q = 0; q < PF; q++) {
           cx[q] = sig[xidx(i0 + q)];
-          cm[q] = sm[sidx(i0 + q)];
-          ce[q] = se[sidx(i0 + q)];
+          cm[q] = pre_m[sidx(i0 + q)];
+          ce[q] = pre_e[sidx(i0 + q)];
         }
         for (int ub = 0; ub < steps; ub += PF) {
 #pragma unroll
@@ -503,8 +505,8 @@ __global__ __launch_bounds__(64, 3) void ell_kernel(EllArgs g) {
               const X nacc = add_lazy(acc, xm::mul(st.wq[0], sv));  // node.cpp:31-37
               acc = xm::sel(is_fin, nacc, acc);
               cx[q] = sig[xidx(i0 + u + PF)];
-              cm[q] = sm[sidx(i0 + u + PF)];
-              ce[q] = se[sidx(i0 + u + PF)];
+              cm[q] = pre_m[sidx(i0 + u + PF)];
+              ce[q] = pre_e[sidx(i0 + u + PF)];
             }
           }
         }
