@@ -83,7 +83,10 @@ template <int MEL>
 struct LaneState;
 struct HypDesc {
   double bm, bac, bmc;  // the lane's own density, constants scaled for dens::density
-  int wbs, wbe, ebe, pbs, pbe, has_wob;
+  double wobf;          // exp(-2) if the lane has a wobble row, else 0
+  int wbs, wbe;         // cells of the wobble row (what arrives from the left is taken from wbs on)
+  int elo, ebe;         // cells of the emitting row
+  int has_wob;
 };
 
 // a + b without re-normalising the mantissa (it drifts by a few bits per step at most; the caller
@@ -102,12 +105,12 @@ __device__ __forceinline__ X density_x(double x, double mean, double ac, double 
 // fused_step with lazy sums; gb/ga are the two mixture components at this cell's sample
 template <int MEL>
 __device__ __forceinline__ X fused_step_fast(const HypDesc &d, LaneState<MEL> &st, int i, X gb, X ga,
-                                             X pred, bool on) {
+                                             X pred) {
   X mix = add_lazy(ga, gb);
-  mix.m *= EXPM2_D;
+  mix.m *= d.wobf;                            // (g1 + g2) * exp(-2); no wobble row: a clean zero
+  mix.e = (d.has_wob != 0) ? mix.e : xm::XZ;
   X wn = add_lazy(pred, xm::mul(mix, st.wq[0]));  // node_next_row.h with mel = 0
-  wn = xm::sel(d.has_wob != 0, wn, pred);
-  wn = xm::sel(on && i >= d.wbs && i <= d.wbe, wn, xm::zero());
+  wn = xm::sel(i >= d.wbs && i <= d.wbe, wn, xm::zero());
 #pragma unroll
   for (int k = MEL; k >= 1; k--) st.wq[k] = st.wq[k - 1];
   st.wq[0] = wn;
@@ -118,7 +121,7 @@ __device__ __forceinline__ X fused_step_fast(const HypDesc &d, LaneState<MEL> &s
     for (int k = 0; k < MEL - 1; k++) P = xm::mul(P, st.gh[k]);
   }
   X en = add_lazy(xm::mul(P, st.wq[MEL]), xm::mul(gb, st.em));
-  en = xm::sel(on && i >= MEL && i <= d.ebe, en, xm::zero());
+  en = xm::sel(i >= d.elo && i <= d.ebe, en, xm::zero());
   st.em = en;
   if (MEL >= 2) {
 #pragma unroll
@@ -339,6 +342,10 @@ __global__ __launch_bounds__(64, 3) void ell_kernel(EllArgs g) {
   int32_t *suf_e = pre_e + g.half;
   for (int q = lane; q < g.SR; q += 64) ring[q] = 0.0;
   dens::fill_table(etab, lane, 64);
+  if (lane == 0) {  // the store's last cell is never part of a row: a zero the streams can point at
+    pre_m[g.store_stride - 1] = 0.0;
+    pre_e[g.store_stride - 1] = xm::XZ;
+  }
 
   while (true) {
     __syncthreads();
@@ -422,10 +429,11 @@ __global__ __launch_bounds__(64, 3) void ell_kernel(EllArgs g) {
         const bool is_fin = valid && gl == npos + 1;
         const bool is_in = valid && gl == 1;  // the lane fed by prefix[first]
         HypDesc d;
-        d.wbs = 0x40000000; d.wbe = -0x40000000; d.ebe = -0x40000000; d.pbs = 0; d.pbe = -1;
+        d.wbs = 0x40000000; d.wbe = -0x40000000; d.elo = 0x40000000; d.ebe = -0x40000000;
         d.has_wob = 0; d.bm = 0.0; d.bac = 0.0; d.bmc = 0.0;
         // input stream of the lane: cell i lives at pre_m/pre_e[sbase + i] (the suffix rows follow the
-        // prefix rows in the same store, g.half cells on), valid for i in [slo, shi]
+        // prefix rows in the same store, g.half cells on), valid for i in [slo, shi]; every other cell
+        // reads the store's zero cell
         int sbase = 0, slo = 0x40000000, shi = -0x40000000;
         int64_t idb = -1;
         if (valid && gl == 0) {
@@ -435,7 +443,6 @@ __global__ __launch_bounds__(64, 3) void ell_kernel(EllArgs g) {
           idb = kmer_id_mod(dm, ref, R, cb, nb, ca, na, j, p, b);
           d.has_wob = (j > 0 && g.wobbling) ? 1 : 0;
           d.wbs = bs[j]; d.wbe = be[j]; d.ebe = be[j + 1];
-          d.pbs = d.wbs; d.pbe = d.wbe;
           if (is_in) {
             sbase = rowoff[first] - bs[first];
             slo = bs[first]; shi = be[first];
@@ -446,11 +453,12 @@ __global__ __launch_bounds__(64, 3) void ell_kernel(EllArgs g) {
           d.has_wob = (last + 1 < R && g.wobbling) ? 1 : 0;
           if (d.has_wob) {
             idb = kmer_id_mod(dm, ref, R, cb, nb, ca, na, last + 1, p, b);
-            d.wbs = bs[last]; d.wbe = be[last];
+            // band `last`; the emitting row of `last` only exists from bs[last+1] on, and nothing
+            // can be in the wobble row before its first value arrives
+            d.wbs = max(bs[last], bs[last + 1]); d.wbe = be[last];
           } else {
             d.wbs = bs[last + 1]; d.wbe = be[last + 1];
           }
-          d.pbs = bs[last + 1]; d.pbe = be[last + 1];
           d.ebe = d.wbe;
           sbase = (int)g.half + rowoff[last + 1] - bs[last + 1];
           slo = bs[last + 1]; shi = be[last + 1];
@@ -459,6 +467,8 @@ __global__ __launch_bounds__(64, 3) void ell_kernel(EllArgs g) {
           d.bm = dm.mean[idb];
           dens::scale_consts(dm.ac[idb], dm.mc[idb], d.bac, d.bmc);
         }
+        d.wobf = d.has_wob ? EXPM2_D : 0.0;
+        d.elo = max(d.wbs, MEL);
         const int base = valid ? bs[first] : 0;
         int steps = 0;
         if (is_fin) steps = d.wbe - base + gl + 1;
@@ -466,7 +476,7 @@ __global__ __launch_bounds__(64, 3) void ell_kernel(EllArgs g) {
         steps = __builtin_amdgcn_readfirstlane(steps);  // uniform trip count
         const int i0 = base - gl;
         // clamped, unsigned element offsets from uniform base pointers (scalar base + 32-bit offset)
-        auto sidx = [&](int i) { return (unsigned)min(max(sbase + i, 0), smax); };
+        auto sidx = [&](int i) { return (unsigned)((i >= slo && i <= shi) ? sbase + i : smax); };
         auto xidx = [&](int i) { return (unsigned)min(max(i - 1, 0), N - 1); };
         LaneState<MEL> st;
         st.reset();
@@ -492,18 +502,17 @@ __global__ __launch_bounds__(64, 3) void ell_kernel(EllArgs g) {
                 st.em = xm::norm(st.em);
                 acc = xm::norm(acc);
               }
-              X sv{cm[q], ce[q]};
-              sv = xm::sel(i >= slo && i <= shi, sv, xm::zero());
+              const X sv{cm[q], ce[q]};  // zero outside the stream's band (zero cell)
               const X ga = dpp_shr1(gb_last);
-              X pred = dpp_shr1(st.em);  // emitting row of the lane to the left, one step ago
-              if (is_in) pred = sv;      // prefix[first] (already masked to its band)
-              pred = xm::sel(i >= d.pbs && i <= d.pbe, pred, xm::zero());
-              const bool on = (is_pos || is_fin) && i >= d.wbs && i <= d.ebe;
+              // the emitting row of the lane to the left, one step ago: zero beyond its last cell, and
+              // only taken from the wobble row's first cell on
+              X pred = dpp_shr1(st.em);
+              if (is_in) pred = sv;  // prefix[first]
               const X gb = density_x(cx[q], d.bm, d.bac, d.bmc, etab);
-              (void)fused_step_fast<MEL>(d, st, i, gb, ga, pred, on);
+              (void)fused_step_fast<MEL>(d, st, i, gb, ga, pred);
               gb_last = gb;
-              const X nacc = add_lazy(acc, xm::mul(st.wq[0], sv));  // node.cpp:31-37
-              acc = xm::sel(is_fin, nacc, acc);
+              // node.cpp:31-37; only the closing lane's total is used (the other lanes sum garbage)
+              acc = add_lazy(acc, xm::mul(st.wq[0], sv));
               cx[q] = sig[xidx(i0 + u + PF)];
               cm[q] = pre_m[sidx(i0 + u + PF)];
               ce[q] = pre_e[sidx(i0 + u + PF)];
