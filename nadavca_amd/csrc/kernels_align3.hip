@@ -40,8 +40,8 @@ using dens::ETN;
 
 constexpr int CH = 64;      // signal refill chunk (samples)
 constexpr int PF = 4;       // forward sweep: spill prefetch depth (steps)
-constexpr int RSH = 4;
-constexpr int RS = 1 << RSH;  // rescale period (steps); must exceed c + mel
+// rescale period: 2^rsh steps (launch parameter, >= 16); must exceed c + mel so that at most one
+// rescale lies inside the window a neighbour value travels through
 constexpr int GBIG = 1 << 24;  // scale of an empty running maximum (see the path step)
 constexpr int TARGET = 250; // exponent the largest live value is moved to
 #define HUGE_V 0x1.0p+900
@@ -83,7 +83,9 @@ struct Align3Args {
   int *counter;
   int H, SR;
   int transitions;
-  int c_cap;
+  int c_lo, c_cap;  // this launch serves reads with c_lo < c <= c_cap
+  int flag_above;   // ... and hands reads with c > c_cap to the exact kernel (last launch only)
+  int rsh;          // log2 of the rescale period
   int *n_retry;      // reads handed to the exact kernel
   int32_t *out_events;
   int32_t *out_status;
@@ -193,8 +195,9 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
       if (lane == 0) g.out_status[rd] = m.status;
       continue;
     }
-    if (m.c > g.c_cap) {  // band too wide for this launch's LDS rings: exact kernel
-      if (lane == 0) {
+    if (m.c <= g.c_lo) continue;  // served by the launch with the smaller rings
+    if (m.c > g.c_cap) {           // band too wide for this launch's LDS rings
+      if (g.flag_above && lane == 0) {
         g.out_status[rd] = NVK_READ_RETRY_INTERNAL;
         atomicAdd(g.n_retry, 1);
       }
@@ -213,6 +216,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
     int K = 0;          // true exponent of the largest suffix[0][.]
     bool suspect = false;  // something left the double range: the exact kernel must redo this read
     const int sA0 = ((-c - MEL) % H + H) % H, sB0 = ((-c) % H + H) % H;
+    const int RSH = g.rsh, RS = 1 << RSH;
 
     // =========================== reverse sweep: suffix rows -> spill ===========================
     {
@@ -623,33 +627,9 @@ int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadM
   }
   const int max_c = tot.max_c < 1 ? 1 : tot.max_c;
   const int max_steps = tot.max_steps < 1 ? 1 : tot.max_steps;
-  const int c = max_c < ALIGN1_C_CAP ? max_c : ALIGN1_C_CAP;  // wider reads go to the exact kernel
-  if (c + mel + 1 >= RS) return NVK_ERR_UNSUPPORTED;
-  // history ring: ages 1 .. c+mel are read; the oldest slot is read and then overwritten in the same
-  // step (LDS operations of one wave execute in program order)
-  const int H = c + mel;
-  int SR = 256;
-  while (SR < 64 * c + CH) SR <<= 1;
-  size_t lds = (size_t)ETN * 8 + (size_t)SR * 8 + (size_t)H * 64 * 20 + 16;
-  int per_cu = (int)((160 * 1024) / lds);
-  if (per_cu > 16) per_cu = 16;
-  if (per_cu < 1) per_cu = 1;
-  int64_t slots = ctx->slots_override > 0 ? ctx->slots_override : (int64_t)ctx->num_cus * per_cu;
-  if (slots > a.n_reads) slots = a.n_reads;
-  const int64_t spill_stride = ((int64_t)max_steps + 2 * PF) * 64;
-  const int64_t L_stride = (int64_t)(max_steps >> RSH) + 4;
-  const int64_t bp_stride = (int64_t)((max_steps + 31) / 32 + 1) * 64;
-  const int64_t cap = (int64_t)48 << 30;
-  while (slots > 1 && slots * spill_stride * 8 > cap) slots /= 2;
-  int rc = nvk_ws_reserve(ctx, WS_SPILL, (size_t)slots * spill_stride * 8);
-  if (rc) return rc;
-  rc = nvk_ws_reserve(ctx, WS_STAGE, (size_t)slots * L_stride * 4);
-  if (rc) return rc;
-  rc = nvk_ws_reserve(ctx, WS_BP, (size_t)slots * bp_stride * 4);
-  if (rc) return rc;
-  rc = nvk_ws_reserve(ctx, WS_MISC, 256);
-  if (rc) return rc;
   const int64_t rows_total = transitions ? 2 * a.total_ref : a.total_ref + a.n_reads;
+  int rc = nvk_ws_reserve(ctx, WS_MISC, 256);
+  if (rc) return rc;
   rc = nvk_ws_reserve(ctx, WS_LANE_F, (size_t)(rows_total + 1) * sizeof(Lane3));
   if (rc) return rc;
   rc = nvk_ws_reserve(ctx, WS_LANE_R, (size_t)(rows_total + 1) * sizeof(Lane3));
@@ -657,27 +637,6 @@ int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadM
   int *counter = (int *)ctx->ws[WS_MISC];
   int *d_retry = counter + 2;
   NVK_HIP(hipMemsetAsync(counter, 0, 4 * sizeof(int), ctx->stream));
-
-  Align3Args g;
-  g.metas = metas;
-  g.fwdl = (const Lane3 *)ctx->ws[WS_LANE_F];
-  g.revl = (const Lane3 *)ctx->ws[WS_LANE_R];
-  g.signal = a.signal;
-  g.spill_v = (double *)ctx->ws[WS_SPILL];
-  g.spill_L = (int32_t *)ctx->ws[WS_STAGE];
-  g.bp = (uint32_t *)ctx->ws[WS_BP];
-  g.spill_stride = spill_stride;
-  g.L_stride = L_stride;
-  g.bp_stride = bp_stride;
-  g.n_reads = (int)a.n_reads;
-  g.counter = counter;
-  g.H = H;
-  g.SR = SR;
-  g.transitions = transitions;
-  g.c_cap = ALIGN1_C_CAP;
-  g.n_retry = d_retry;
-  g.out_events = out_events;
-  g.out_status = out_status;
 
   void (*kern)(Align3Args) = nullptr;
   switch (mel) {
@@ -693,14 +652,81 @@ int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadM
                        (Lane3 *)ctx->ws[WS_LANE_F], (Lane3 *)ctx->ws[WS_LANE_R], (int)a.n_reads);
   }
   NVK_HIP(hipGetLastError());
-  {
-    TimerScope ts(ctx, NVK_K_ALIGN);
-    hipLaunchKernelGGL(kern, dim3((unsigned)slots), dim3(64), lds, ctx->stream, g);
+
+  // Two launches: the LDS rings are sized by the largest skew a launch serves, so the (usual) reads
+  // with c <= ALIGN1_C_CAP keep their 16 waves per CU whatever else is in the batch; wide-band reads
+  // (long reads, BASELINE config 5) run with larger rings and a longer rescale period.
+  const int C_HARD = 58;  // rescale period 64 must exceed c + mel + 1
+  struct Cls { int lo, hi; int64_t reads; };
+  Cls cls[2];
+  int ncls = 0;
+  const int64_t n_wide = (int64_t)tot.n_wide;
+  if (a.n_reads - n_wide > 0 || max_c <= ALIGN1_C_CAP)
+    cls[ncls++] = Cls{0, max_c < ALIGN1_C_CAP ? max_c : ALIGN1_C_CAP, a.n_reads - n_wide};
+  if (max_c > ALIGN1_C_CAP) cls[ncls++] = Cls{ALIGN1_C_CAP, max_c < C_HARD ? max_c : C_HARD, n_wide};
+  for (int k = 0; k < ncls; k++) {
+    const int c = cls[k].hi;
+    int rsh = 4;
+    while ((1 << rsh) <= c + mel + 1) rsh++;
+    // history ring: ages 1 .. c+mel are read; the oldest slot is read and then overwritten in the
+    // same step (LDS operations of one wave execute in program order)
+    const int H = c + mel > 0 ? c + mel : 1;
+    int SR = 256;
+    while (SR < 64 * c + CH) SR <<= 1;
+    size_t lds = (size_t)ETN * 8 + (size_t)SR * 8 + (size_t)H * 64 * 20 + 16;
+    if (lds > 160 * 1024) return NVK_ERR_UNSUPPORTED;
+    int per_cu = (int)((160 * 1024) / lds);
+    if (per_cu > 16) per_cu = 16;
+    if (per_cu < 1) per_cu = 1;
+    int64_t slots = ctx->slots_override > 0 ? ctx->slots_override : (int64_t)ctx->num_cus * per_cu;
+    if (slots > cls[k].reads) slots = cls[k].reads > 0 ? cls[k].reads : 1;
+    const int64_t spill_stride = ((int64_t)max_steps + 2 * PF) * 64;
+    const int64_t L_stride = (int64_t)(max_steps >> rsh) + 4;
+    const int64_t bp_stride = (int64_t)((max_steps + 31) / 32 + 1) * 64;
+    const int64_t cap = (int64_t)48 << 30;
+    while (slots > 1 && slots * spill_stride * 8 > cap) slots /= 2;
+    rc = nvk_ws_reserve(ctx, WS_SPILL, (size_t)slots * spill_stride * 8);
+    if (rc) return rc;
+    rc = nvk_ws_reserve(ctx, WS_STAGE, (size_t)slots * L_stride * 4);
+    if (rc) return rc;
+    rc = nvk_ws_reserve(ctx, WS_BP, (size_t)slots * bp_stride * 4);
+    if (rc) return rc;
+    NVK_HIP(hipMemsetAsync(counter, 0, sizeof(int), ctx->stream));
+
+    Align3Args g;
+    g.metas = metas;
+    g.fwdl = (const Lane3 *)ctx->ws[WS_LANE_F];
+    g.revl = (const Lane3 *)ctx->ws[WS_LANE_R];
+    g.signal = a.signal;
+    g.spill_v = (double *)ctx->ws[WS_SPILL];
+    g.spill_L = (int32_t *)ctx->ws[WS_STAGE];
+    g.bp = (uint32_t *)ctx->ws[WS_BP];
+    g.spill_stride = spill_stride;
+    g.L_stride = L_stride;
+    g.bp_stride = bp_stride;
+    g.n_reads = (int)a.n_reads;
+    g.counter = counter;
+    g.H = H;
+    g.SR = SR;
+    g.transitions = transitions;
+    g.c_lo = cls[k].lo;
+    g.c_cap = cls[k].hi;
+    g.flag_above = (k == ncls - 1) ? 1 : 0;
+    g.rsh = rsh;
+    g.n_retry = d_retry;
+    g.out_events = out_events;
+    g.out_status = out_status;
+    if (lds > 64 * 1024)
+      NVK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    {
+      TimerScope ts(ctx, NVK_K_ALIGN);
+      hipLaunchKernelGGL(kern, dim3((unsigned)slots), dim3(64), lds, ctx->stream, g);
+    }
+    NVK_HIP(hipGetLastError());
   }
-  NVK_HIP(hipGetLastError());
   NVK_HIP(hipMemcpyAsync(n_retry, d_retry, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   NVK_HIP(hipStreamSynchronize(ctx->stream));
   // bytes the sweeps stream through HBM: 8 B written + 8 B read per (step, lane) + scales + bits
-  ctx->last_spill_bytes = (int64_t)tot.steps * 64 * 16 + (int64_t)tot.steps / RS * 8 + (int64_t)tot.steps * 8 * 2;
+  ctx->last_spill_bytes = (int64_t)tot.steps * 64 * 16 + (int64_t)tot.steps / 16 * 8 + (int64_t)tot.steps * 8 * 2;
   return NVK_OK;
 }
