@@ -100,3 +100,25 @@ def test_long_read_wide_band(dtw, oracle_port):
         got = dtw.refine_alignment(*a, mg, tr)
         exp = oracle_port.refine_alignment(*a, mo, tr)
         assert np.array_equal(got, exp)
+
+
+def test_mixed_narrow_and_wide_reads_in_one_batch(dtw, oracle_port):
+    """A batch whose reads need different wavefront skews is served by two launches of the default
+    kernel (small rings for the usual reads, large rings + longer rescale period for wide bands);
+    every read must come out as if it had been aligned alone."""
+    from nadavca_amd import synthetic
+    model = synthetic.load_model_arrays()
+    mg = dtw.KmerModel(*model)
+    mo = oracle_port.KmerModel(*model)
+    cases = []
+    for i, (R, jit) in enumerate([(60, 4), (700, 40), (45, 3), (900, 60), (30, 2)]):
+        rng = np.random.default_rng([906, i])
+        cases.append(synthetic.make_dp_case(rng, model, R=R, bandwidth=400, jitter=jit, anchor_density=0.5))
+    reads = [(c['signal'], c['reference'], c['context_before'], c['context_after'], c['approximate_alignment'])
+             for c in cases]
+    for tr in (True, False):
+        got = dtw.refine_alignment_batch(reads, 400, 2, mg, tr)
+        for c, ev in zip(cases, got):
+            exp = oracle_port.refine_alignment(c['signal'], c['reference'], c['context_before'], c['context_after'],
+                                               c['approximate_alignment'], 400, 2, mo, tr)
+            assert np.array_equal(ev, exp)

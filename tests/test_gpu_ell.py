@@ -114,3 +114,39 @@ def test_ell_config_sized_vs_oracle(dtw, oracle_port):
         assert np.all(col == col[0])
         # and the true base is the most likely one almost everywhere on clean synthetic data
         assert np.mean(np.argmax(ll, axis=1) == ref) > 0.95
+
+
+def test_ell_exact_variant_matches(golden_config):
+    """NADAVCA_ELL_KERNEL=1 selects the original hypothesis phase (two polynomial densities per lane,
+    LDS hand-over); it must reproduce the fixtures like the default one (child process: the variant is
+    read from the environment at call time)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r + "/tests")
+from conftest import GoldenFile
+from nadavca_amd import dtw
+for name in ("dp_tiny.npz", "dp_config.npz"):
+    g = GoldenFile(name)
+    k, c, a, mean, sigma = g.model
+    m = dtw.KmerModel(k, c, a, mean, sigma)
+    groups = {}
+    for case in g.cases:
+        groups.setdefault((int(case["bandwidth"]), int(case["min_event_length"])), []).append(case)
+    for (bw, mel), cases in groups.items():
+        reads = [(x["signal"], x["reference"], x["context_before"], x["context_after"], x["approximate_alignment"]) for x in cases]
+        for w in (0, 1):
+            got = dtw.estimate_log_likelihoods_batch(reads, bw, mel, m, bool(w))
+            for case, ll in zip(cases, got):
+                exp = case["ell_w%%d" %% w]
+                assert np.array_equal(np.isneginf(ll), np.isneginf(exp))
+                fin = np.isfinite(exp)
+                assert np.allclose(ll[fin], exp[fin], rtol=1e-9, atol=1e-9)
+print("ELL-EXACT-OK")
+""" % (ROOT, ROOT)
+    env = dict(os.environ, NADAVCA_ELL_KERNEL='1')
+    p = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and 'ELL-EXACT-OK' in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
