@@ -322,15 +322,139 @@ __device__ void sweep(const FusedParam *desc, int R, int N, int c, const double 
   }
 }
 
+// The same sweep with the arithmetic of the fast hypothesis phase: lazy sums, one table density per
+// lane; the mixture's other component is the left neighbour's own density at the same cell, which the
+// neighbour evaluated c steps earlier and hands over through the LDS ring together with its emitting
+// value (24 B per lane and slot).
+// what a fast-sweep lane needs of a FusedParam (48 B instead of 80 B in the LDS window)
+struct __attribute__((aligned(16))) SweepLane {
+  double bm, bac, bmc;  // the emitting Gaussian, constants scaled for dens::density
+  int32_t wbs, wbe, ebe, ebs, soff, has_wob;
+};
+static_assert(sizeof(SweepLane) == 48, "SweepLane layout");
+
+__device__ __forceinline__ void load_lane_block(SweepLane *tab, const FusedParam *src, int blk, int R,
+                                                int lane) {
+  int j = blk * 64 + lane;
+  if (j >= 0 && j < R) {
+    const FusedParam f = src[j];
+    SweepLane l;
+    l.bm = f.b_mean;
+    dens::scale_consts(f.b_ac, f.b_mc, l.bac, l.bmc);
+    l.wbs = f.wbs; l.wbe = f.wbe; l.ebe = f.ebe; l.ebs = f.ebs; l.soff = f.store_off;
+    l.has_wob = f.has_wob;
+    tab[j & (TABN - 1)] = l;
+  }
+}
+
+template <int MEL>
+__device__ void sweep_fast(const FusedParam *desc, int R, int N, int c, const double *sig, bool mirror,
+                           double *ring, int RM, SweepLane *tab, const double *etab, double *hist_m,
+                           double *hist_g, int *hist_e, int H, double *st_m, int32_t *st_e, int lane) {
+  int r_old = 0, loaded_hi = 0;
+  load_lane_block(tab, desc, 0, R, lane);
+  __syncthreads();
+  int j = lane;
+  HypDesc d;
+  int ebs = 0, soff = 0;
+  auto take = [&](const SweepLane &f) {
+    d.bm = f.bm; d.bac = f.bac; d.bmc = f.bmc;
+    d.has_wob = f.has_wob;
+    d.wobf = f.has_wob ? EXPM2_D : 0.0;
+    d.wbs = f.wbs; d.wbe = f.wbe; d.ebe = f.ebe;
+    d.elo = max(f.wbs, MEL);
+    ebs = f.ebs; soff = f.soff;
+  };
+  auto dead = [&]() {
+    d.wbs = 0x40000000; d.wbe = -0x40000000; d.elo = 0x40000000; d.ebe = -0x40000000;
+  };
+  d.bm = d.bac = d.bmc = d.wobf = 0.0; d.has_wob = 0;
+  dead();
+  if (j < R) take(tab[j & (TABN - 1)]);
+  const int t_min = __builtin_amdgcn_readfirstlane(d.wbs);
+  const FusedParam &lastf = desc[R - 1];
+  const int t_max = lastf.ebe + c * (R - 1);
+  const int n_steps = __builtin_amdgcn_readfirstlane(t_max - t_min + 1);
+  LaneState<MEL> st;
+  st.reset();
+  int i = t_min - c * j;
+  int filled_hi = ((t_min - 1) > 0 ? (t_min - 1) / CH : 0) * CH;
+  auto fill = [&](int upto) {
+    while (upto >= filled_hi) {
+      __syncthreads();
+      for (int w = lane; w < CH; w += 64) {
+        int idx = filled_hi + w;
+        int src = mirror ? (N - 1 - idx) : idx;
+        ring[idx & RM] = (idx >= 0 && idx < N) ? sig[src] : 0.0;
+      }
+      filled_hi += CH;
+      __syncthreads();
+    }
+  };
+  fill(t_min);
+  int su = 0, sr = ((-c) % H + H) % H;
+  for (int u = 0; u < n_steps; ++u) {
+    const int t = t_min + u;
+    bool fin = (i > d.ebe) && (j < R);
+    if (__any(fin)) {
+      int nj = j + 64;
+      if (__any(fin && nj < R && (nj >> 6) > loaded_hi)) {
+        loaded_hi++;
+        load_lane_block(tab, desc, loaded_hi, R, lane);
+        __syncthreads();
+      }
+      if (fin) {
+        j = nj;
+        i -= 64 * c;
+        st.reset();
+        if (j < R) take(tab[j & (TABN - 1)]);
+        else dead();
+      }
+      while (r_old < R && __builtin_amdgcn_readlane(j, r_old & 63) != r_old) r_old++;
+    }
+    if (r_old < R) fill(t - c * r_old);
+    if ((u & (HRS - 1)) == HRS - 1) {  // keep the lazily summed mantissas near 1
+      asm volatile("");
+#pragma unroll
+      for (int k = 0; k <= MEL; k++) st.wq[k] = xm::norm(st.wq[k]);
+      st.em = xm::norm(st.em);
+    }
+    const double x = ring[(i - 1) & RM];
+    const int hs = sr * 64 + ((lane - 1) & 63);
+    // left neighbour, c steps ago, same cell: its emitting value (zero beyond its last cell; only
+    // taken from the wobble row's first cell on) and its density
+    X pred{hist_m[hs], hist_e[2 * hs]};
+    const X ga{hist_g[hs], hist_e[2 * hs + 1]};
+    if (j == 0) pred = xm::one();  // prefix[0] / suffix[R]: all ones on their band
+    const X gb = density_x(x, d.bm, d.bac, d.bmc, etab);
+    const X en = fused_step_fast<MEL>(d, st, i, gb, ga, pred);
+    const int hw = su * 64 + lane;
+    hist_m[hw] = en.m;
+    hist_g[hw] = gb.m;
+    *reinterpret_cast<int2 *>(hist_e + 2 * hw) = make_int2(en.e, gb.e);
+    if (i >= ebs && i <= d.ebe) {  // row-major store, un-mirrored cell index
+      int off = soff + (mirror ? (d.ebe - i) : (i - ebs));
+      st_m[off] = en.m;
+      st_e[off] = en.e;
+    }
+    i += 1;
+    su = (su + 1 == H) ? 0 : su + 1;
+    sr = (sr + 1 == H) ? 0 : sr + 1;
+    WAVE_SYNC();
+  }
+}
+
 template <int MEL, bool FAST>
 __global__ __launch_bounds__(64, 3) void ell_kernel(EllArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double *etab = reinterpret_cast<double *>(smem);
   double *ring = etab + dens::ETN;
   FusedParam *tab = reinterpret_cast<FusedParam *>(ring + g.SR);
-  double *hist_m = reinterpret_cast<double *>(tab + TABN);
-  int *hist_e = reinterpret_cast<int *>(hist_m + (size_t)g.H * 64);
-  int *s_read = hist_e + (size_t)g.H * 64;
+  double *hist_m = FAST ? reinterpret_cast<double *>(reinterpret_cast<SweepLane *>(tab) + TABN)
+                        : reinterpret_cast<double *>(tab + TABN);
+  double *hist_g = hist_m + (size_t)g.H * 64;  // (fast sweeps) the lanes' own densities
+  int *hist_e = reinterpret_cast<int *>(hist_g + (size_t)g.H * 64);
+  int *s_read = hist_e + (size_t)g.H * 64 * 2;
 
   const int lane = threadIdx.x;
   const int RM = g.SR - 1;
@@ -382,11 +506,20 @@ __global__ __launch_bounds__(64, 3) void ell_kernel(EllArgs g) {
       suf_e[rowoff[R] + x - bs[R]] = 1;
     }
     // ---- A, B: the two sweeps
-    sweep<MEL>(g.pl.fwd + m.row_off, R, N, c, sig, false, ring, RM, tab, hist_m, hist_e, g.H, pre_m,
-               pre_e, lane);
-    __syncthreads();
-    sweep<MEL>(g.pl.rev + m.row_off, R, N, c, sig, true, ring, RM, tab, hist_m, hist_e, g.H, suf_m,
-               suf_e, lane);
+    if (FAST) {
+      SweepLane *ltab = reinterpret_cast<SweepLane *>(tab);  // same window, smaller entries
+      sweep_fast<MEL>(g.pl.fwd + m.row_off, R, N, c, sig, false, ring, RM, ltab, etab, hist_m, hist_g,
+                      hist_e, g.H, pre_m, pre_e, lane);
+      __syncthreads();
+      sweep_fast<MEL>(g.pl.rev + m.row_off, R, N, c, sig, true, ring, RM, ltab, etab, hist_m, hist_g,
+                      hist_e, g.H, suf_m, suf_e, lane);
+    } else {
+      sweep<MEL>(g.pl.fwd + m.row_off, R, N, c, sig, false, ring, RM, tab, hist_m, hist_e, g.H, pre_m,
+                 pre_e, lane);
+      __syncthreads();
+      sweep<MEL>(g.pl.rev + m.row_off, R, N, c, sig, true, ring, RM, tab, hist_m, hist_e, g.H, suf_m,
+                 suf_e, lane);
+    }
     __syncthreads();
 
     // ---- no-substitution likelihood: sum_x prefix[R][x] * suffix[R][x]  (dtw.cpp:83-85)
@@ -663,7 +796,13 @@ int launch_ell(nvk_ctx *ctx, const DeviceModel &dm, const BatchArgs &a, int wobb
   if (H < 2) H = 2;
   int SR = 256;
   while (SR < 64 * c + CH) SR <<= 1;
-  size_t lds = (size_t)dens::ETN * 8 + (size_t)SR * 8 + (size_t)TABN * sizeof(FusedParam) + (size_t)H * 64 * 12 + 16;
+  // default: the fast variant; NADAVCA_ELL_KERNEL=1 (or a k-mer too long for its lane layout)
+  // selects the original formulation
+  const char *force = getenv("NADAVCA_ELL_KERNEL");
+  const bool fast = !(force && force[0] == '1') && dm.k + 2 <= GL;
+  size_t lds_fast = (size_t)dens::ETN * 8 + (size_t)SR * 8 + (size_t)TABN * sizeof(SweepLane) + (size_t)H * 64 * 24 + 16;
+  size_t lds_exact = (size_t)dens::ETN * 8 + (size_t)SR * 8 + (size_t)TABN * sizeof(FusedParam) + (size_t)H * 64 * 24 + 16;
+  const size_t lds = fast ? lds_fast : lds_exact;
   if (lds > 160 * 1024) {
     nvk_set_error("band too wide for one wave per read: skew %d needs %zu bytes of LDS", c, lds);
     return NVK_ERR_UNSUPPORTED;
@@ -685,10 +824,6 @@ int launch_ell(nvk_ctx *ctx, const DeviceModel &dm, const BatchArgs &a, int wobb
   if (rc) return rc;
   int *counter = (int *)ctx->ws[WS_MISC];
   NVK_HIP(hipMemsetAsync(counter, 0, sizeof(int), ctx->stream));
-  // default: the fast hypothesis phase; NADAVCA_ELL_KERNEL=1 (or a k-mer too long for its lane
-  // layout) selects the original formulation
-  const char *force = getenv("NADAVCA_ELL_KERNEL");
-  const bool fast = !(force && force[0] == '1') && dm.k + 2 <= GL;
 
   EllArgs g;
   g.dm = dm;
