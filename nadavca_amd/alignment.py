@@ -112,8 +112,21 @@ class ApproximateAligner:
         """(read base, reference base) pairs -> (signal index, reference base) for the bases the
         basecaller placed on the signal (alignment.py:54-60)."""
         m = read.sequence_to_signal_mapping
-        rows = [(m[int(a)], int(b)) for a, b in base_mapping if int(a) in m]
-        return numpy.array(rows, dtype=int).reshape(-1, 2)
+        cached = getattr(read, '_dense_signal_map', None)
+        if cached is None or cached[0] is not m or cached[1] != len(m):
+            keys = numpy.fromiter(m.keys(), dtype=numpy.int64, count=len(m))
+            vals = numpy.fromiter(m.values(), dtype=numpy.int64, count=len(m))
+            dense = numpy.full(int(keys.max()) + 1 if len(keys) else 0, -1, dtype=numpy.int64)
+            dense[keys] = vals
+            cached = (m, len(m), dense)
+            read._dense_signal_map = cached
+        dense = cached[2]
+        bm = numpy.asarray(base_mapping, dtype=numpy.int64).reshape(-1, 2)
+        a = bm[:, 0]
+        inside = (a >= 0) & (a < dense.size)
+        sig = numpy.where(inside, dense[numpy.where(inside, a, 0)] if dense.size else -1, -1)
+        have = sig >= 0
+        return numpy.stack([sig[have], bm[have, 1]], axis=1).astype(int).reshape(-1, 2)
 
     def get_signal_alignment(self, read, bandwidth):
         base_alignment = self._get_base_alignment(read)
