@@ -472,7 +472,8 @@ extern "C" int nvk_refine_alignment_batch_dev(
   //   default                  kernels_align3.hip (plain doubles, wave-uniform scale) with
   //                            kernels_align.hip as the exact fallback for reads it flags
   //   NADAVCA_ALIGN_KERNEL=1   kernels_align.hip only (mantissa+exponent per value)
-  //   NADAVCA_ALIGN_KERNEL=2   kernels_align2.hip (fused lanes, two reads per wave)
+  //   NADAVCA_ALIGN_KERNEL=2   kernels_align4.hip (fused lanes, two reads per wave, plain doubles
+  //                            under a per-half scale; same exact fallback)
   const char *force = getenv("NADAVCA_ALIGN_KERNEL");
   ctx->last_retries = 0;
   bool use_v1 = !(force && force[0] == '2');
@@ -495,7 +496,18 @@ extern "C" int nvk_refine_alignment_batch_dev(
     NVK_HIP(hipStreamSynchronize(ctx->stream));
     ctx->last_cells = (int64_t)tot.cells;
     ctx->last_steps = (int64_t)tot.steps;
-    rc = launch_align2(ctx, a, model_transitions ? 1 : 0, pl, tot, out_events, out_status);
+    {
+      int n_retry = 0;
+      rc = launch_align4(ctx, a, model_transitions ? 1 : 0, pl, tot, out_events, out_status, &n_retry);
+      ctx->last_retries = n_retry;
+      if (rc == NVK_OK && n_retry > 0) {  // flagged reads: exact kernel (own planner, same inputs)
+        rc = plan_batch(model, a, model_transitions ? PLAN_ALIGN_TRANS : PLAN_ALIGN_PLAIN, 0, tot);
+        if (rc) return rc;
+        rc = launch_align_retry(ctx, a, model_transitions ? 1 : 0, (const ReadMeta *)ctx->ws[WS_META],
+                                (const RowParam *)ctx->ws[WS_ROWS], tot, out_events, out_status);
+        if (rc) return rc;
+      }
+    }
     if (rc == NVK_ERR_UNSUPPORTED) use_v1 = true;  // band too wide for the paired layout
     else if (rc) return rc;
   }

@@ -83,7 +83,6 @@ template <int MEL>
 struct LaneState;
 struct HypDesc {
   double bm, bac, bmc;  // the lane's own density, constants scaled for dens::density
-  double wobf;          // exp(-2) if the lane has a wobble row, else 0
   int wbs, wbe;         // cells of the wobble row (what arrives from the left is taken from wbs on)
   int elo, ebe;         // cells of the emitting row
   int has_wob;
@@ -106,8 +105,11 @@ __device__ __forceinline__ X density_x(double x, double mean, double ac, double 
 template <int MEL>
 __device__ __forceinline__ X fused_step_fast(const HypDesc &d, LaneState<MEL> &st, int i, X gb, X ga,
                                              X pred) {
+  // (g1 + g2) * exp(-2).  Without a wobble row the factor is a clean zero by SELECT: what arrives
+  // as `ga` may then be anything (LDS left-overs, the DPP fill value), including NaN, and 0 * NaN
+  // would leak it into the row.
   X mix = add_lazy(ga, gb);
-  mix.m *= d.wobf;                            // (g1 + g2) * exp(-2); no wobble row: a clean zero
+  mix.m = (d.has_wob != 0) ? mix.m * EXPM2_D : 0.0;
   mix.e = (d.has_wob != 0) ? mix.e : xm::XZ;
   X wn = add_lazy(pred, xm::mul(mix, st.wq[0]));  // node_next_row.h with mel = 0
   wn = xm::sel(i >= d.wbs && i <= d.wbe, wn, xm::zero());
@@ -360,7 +362,6 @@ __device__ void sweep_fast(const FusedParam *desc, int R, int N, int c, const do
   auto take = [&](const SweepLane &f) {
     d.bm = f.bm; d.bac = f.bac; d.bmc = f.bmc;
     d.has_wob = f.has_wob;
-    d.wobf = f.has_wob ? EXPM2_D : 0.0;
     d.wbs = f.wbs; d.wbe = f.wbe; d.ebe = f.ebe;
     d.elo = max(f.wbs, MEL);
     ebs = f.ebs; soff = f.soff;
@@ -368,7 +369,7 @@ __device__ void sweep_fast(const FusedParam *desc, int R, int N, int c, const do
   auto dead = [&]() {
     d.wbs = 0x40000000; d.wbe = -0x40000000; d.elo = 0x40000000; d.ebe = -0x40000000;
   };
-  d.bm = d.bac = d.bmc = d.wobf = 0.0; d.has_wob = 0;
+  d.bm = d.bac = d.bmc = 0.0; d.has_wob = 0;
   dead();
   if (j < R) take(tab[j & (TABN - 1)]);
   const int t_min = __builtin_amdgcn_readfirstlane(d.wbs);
@@ -600,7 +601,6 @@ __global__ __launch_bounds__(64, 3) void ell_kernel(EllArgs g) {
           d.bm = dm.mean[idb];
           dens::scale_consts(dm.ac[idb], dm.mc[idb], d.bac, d.bmc);
         }
-        d.wobf = d.has_wob ? EXPM2_D : 0.0;
         d.elo = max(d.wbs, MEL);
         const int base = valid ? bs[first] : 0;
         int steps = 0;

@@ -403,7 +403,7 @@ __global__ __launch_bounds__(64) void plan_ell_kernel(DeviceModel dm, BatchArgs 
 
 
 // ---------------------------------------------------------------------------------------------
-// planner for refine_alignment v2 (fused lanes, see kernels_align2.hip): lane tables of the
+// planner for refine_alignment v2 (fused lanes, see kernels_align4.hip): lane tables of the
 // prefix sweep and of the mirrored suffix sweep, common skew c.
 // Row layout restated from dtw.cpp:144-180: with transitions the rows are
 //   0 (start, band 0), then per base j: 2j+1 (emit k-mer j, band j+1), 2j+2 (transition j->j+1,

@@ -178,11 +178,11 @@ struct Align2Plan {
 constexpr int NVK_READ_RETRY_INTERNAL = 2;
 constexpr int ALIGN1_C_CAP = 3;  // skew served by the main launch of the one-read-per-wave kernel
 constexpr int ALIGN2_C_CAP = 3;  // skew served by the main launch of the paired kernel
+int launch_align4(nvk_ctx *ctx, const BatchArgs &a, int transitions, const Align2Plan &pl,
+                  const PlanTotals &tot, int32_t *out_events, int32_t *out_status, int *n_retry);
 int launch_plan_align2(nvk_ctx *ctx, const DeviceModel &dm, const BatchArgs &a, int transitions,
                        int c_cap, const Align2Plan &pl, unsigned long long *bandtmp,
                        PlanTotals *totals);
-int launch_align2(nvk_ctx *ctx, const BatchArgs &a, int transitions, const Align2Plan &pl,
-                  const PlanTotals &tot, int32_t *out_events, int32_t *out_status);
 // only_retry != 0: serve only the reads whose out_status is NVK_READ_RETRY_INTERNAL
 int launch_align_retry(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadMeta *metas,
                        const RowParam *rows, const PlanTotals &tot, int32_t *out_events,

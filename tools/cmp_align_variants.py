@@ -17,12 +17,13 @@ for tr in (1, 0):
 print('done')
 ''' % n
 os.makedirs('gpurun_out', exist_ok=True)
-for var in ('0', '1'):
+VARS = (sys.argv[2], sys.argv[3]) if len(sys.argv) > 3 else ('0', '1')
+for var in VARS:
     env = dict(os.environ); env.pop('NADAVCA_ALIGN_KERNEL', None)
     if var != '0': env['NADAVCA_ALIGN_KERNEL'] = var
     subprocess.run([sys.executable, '-c', code], env=env, check=True)
 for tr in (1, 0):
-    a = np.load('gpurun_out/cmp_ev_0_%d.npy' % tr); b = np.load('gpurun_out/cmp_ev_1_%d.npy' % tr)
-    sa = np.load('gpurun_out/cmp_st_0_%d.npy' % tr); sb = np.load('gpurun_out/cmp_st_1_%d.npy' % tr)
+    a = np.load('gpurun_out/cmp_ev_%s_%d.npy' % (VARS[0], tr)); b = np.load('gpurun_out/cmp_ev_%s_%d.npy' % (VARS[1], tr))
+    sa = np.load('gpurun_out/cmp_st_%s_%d.npy' % (VARS[0], tr)); sb = np.load('gpurun_out/cmp_st_%s_%d.npy' % (VARS[1], tr))
     print('transitions', tr, 'reads', len(sa), 'events equal:', np.array_equal(a, b), 'status equal:', np.array_equal(sa, sb),
           'differing rows:', int((a != b).any(axis=1).sum()))
