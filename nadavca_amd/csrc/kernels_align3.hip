@@ -43,6 +43,11 @@ constexpr int PF = 4;       // forward sweep: spill prefetch depth (steps)
 // rescale period: 2^rsh steps (launch parameter, >= 16); must exceed c + mel so that at most one
 // rescale lies inside the window a neighbour value travels through
 constexpr int GBIG = 1 << 24;  // scale of an empty running maximum (see the path step)
+// largest upward move per rescale: when only off-path cells are live (the last rows at the end of a
+// sweep) the wave's largest value can collapse by more than the double range within one period; those
+// values are negligible, so they are allowed to flush instead of dragging the scale (and the next
+// densities' exponents) out of range
+constexpr int DMAX = 512;
 constexpr int TARGET = 250; // exponent the largest live value is moved to
 #define HUGE_V 0x1.0p+900
 #define MASS_TOL 1e-9          // allowed relative spread of the rows' posterior mass
@@ -86,6 +91,7 @@ struct Align3Args {
   int c_lo, c_cap;  // this launch serves reads with c_lo < c <= c_cap
   int flag_above;   // ... and hands reads with c > c_cap to the exact kernel (last launch only)
   int rsh;          // log2 of the rescale period
+  int debug;        // NADAVCA_ALIGN_DEBUG: print where a read first left the double range
   int *n_retry;      // reads handed to the exact kernel
   int32_t *out_events;
   int32_t *out_status;
@@ -325,6 +331,8 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
         // Cells far off the likely path are thousands of bits below the wave's largest value and
         // flush to zero here; that cannot change any value that matters (their contributions are
         // below 2^-53 of it in exact arithmetic too).  Overflow / NaN must never happen.
+        if (g.debug && !(o <= HUGE_V) && !suspect)  // diagnostics: where a read first left the range
+          printf("[align3] read %d reverse step %d row %d cell %d L %d o %g e %g prev %g t1 %g\n", rd, u, r, i, sc.L, o, e, prev, t1);
         suspect |= !(o <= HUGE_V);
         prev = o;
         if (__builtin_amdgcn_readfirstlane(r) == 0) {  // row 0 lives on lane 0; only its kmax is read
@@ -340,7 +348,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
         if (((u + 1) % RS) == 0) {
           int ex = (o != 0.0) ? __builtin_amdgcn_frexp_exp(o) : -0x40000000;
           int mx = wave_max_i(ex);
-          sc.d_next = (mx > -0x40000000) ? (TARGET - mx) : 0;
+          sc.d_next = (mx > -0x40000000) ? min(TARGET - mx, DMAX) : 0;
         }
         i -= 1;
         e3 = e2; e2 = e1; e1 = e;
@@ -491,6 +499,8 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
               asm volatile("");
               if (is_init) o = in_band ? ldexp(1.0, sc.L) : 0.0;
             }
+            if (g.debug && !(o <= HUGE_V) && !suspect)
+              printf("[align3] read %d forward step %d row %d cell %d L %d o %g e %g prev %g t1 %g\n", rd, u, r, i, sc.L, o, e, prev, t1);
             suspect |= !(o <= HUGE_V);
             prev = o;
             // ---- posterior of the cell, on the scale 2^-K:  post = prefix * suffix
@@ -541,7 +551,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
             if (((u + 1) % RS) == 0) {
               int ex = (o != 0.0) ? __builtin_amdgcn_frexp_exp(o) : -0x40000000;
               int mx = wave_max_i(ex);
-              sc.d_next = (mx > -0x40000000) ? (TARGET - mx) : 0;
+              sc.d_next = (mx > -0x40000000) ? min(TARGET - mx, DMAX) : 0;
             }
             i += 1;
             e3 = e2; e2 = e1; e1 = e;
@@ -713,6 +723,7 @@ int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadM
     g.c_cap = cls[k].hi;
     g.flag_above = (k == ncls - 1) ? 1 : 0;
     g.rsh = rsh;
+    g.debug = getenv("NADAVCA_ALIGN_DEBUG") ? 1 : 0;
     g.n_retry = d_retry;
     g.out_events = out_events;
     g.out_status = out_status;

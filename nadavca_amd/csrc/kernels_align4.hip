@@ -55,6 +55,7 @@ constexpr int PF = 4;       // forward sweep: spill prefetch depth (steps)
 constexpr int RSH = 4;
 constexpr int RS = 1 << RSH;  // rescale period (steps); must exceed c + mel
 constexpr int TARGET = 250;   // exponent the largest live value of a half is moved to
+constexpr int DMAX = 512;     // largest upward move per rescale (see kernels_align3.hip)
 constexpr int GBIG = 1 << 24; // scale of an empty running maximum
 constexpr int EBIG = 0x40000000;
 constexpr int C_CAP4 = 5;     // widest skew this kernel's rings are sized for (32 lanes per read)
@@ -389,7 +390,7 @@ __device__ __forceinline__ void sweep(const Half &h, int maxsteps, double *ring,
           if (a != 0.0) ex = __builtin_amdgcn_frexp_exp(a);
           if (b != 0.0) ex = max(ex, __builtin_amdgcn_frexp_exp(b));
           ex = half_max_i(ex);
-          d_next = (ex > -EBIG) ? (TARGET - ex) : 0;
+          d_next = (ex > -EBIG) ? min(TARGET - ex, DMAX) : 0;
         }
         i += 1;
         e3 = e2; e2 = e1; e1 = e;
