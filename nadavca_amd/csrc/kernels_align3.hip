@@ -91,7 +91,6 @@ struct Align3Args {
   int c_lo, c_cap;  // this launch serves reads with c_lo < c <= c_cap
   int flag_above;   // ... and hands reads with c > c_cap to the exact kernel (last launch only)
   int rsh;          // log2 of the rescale period
-  int debug;        // NADAVCA_ALIGN_DEBUG: print where a read first left the double range
   int *n_retry;      // reads handed to the exact kernel
   int32_t *out_events;
   int32_t *out_status;
@@ -331,8 +330,6 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
         // Cells far off the likely path are thousands of bits below the wave's largest value and
         // flush to zero here; that cannot change any value that matters (their contributions are
         // below 2^-53 of it in exact arithmetic too).  Overflow / NaN must never happen.
-        if (g.debug && !(o <= HUGE_V) && !suspect)  // diagnostics: where a read first left the range
-          printf("[align3] read %d reverse step %d row %d cell %d L %d o %g e %g prev %g t1 %g\n", rd, u, r, i, sc.L, o, e, prev, t1);
         suspect |= !(o <= HUGE_V);
         prev = o;
         if (__builtin_amdgcn_readfirstlane(r) == 0) {  // row 0 lives on lane 0; only its kmax is read
@@ -499,8 +496,6 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
               asm volatile("");
               if (is_init) o = in_band ? ldexp(1.0, sc.L) : 0.0;
             }
-            if (g.debug && !(o <= HUGE_V) && !suspect)
-              printf("[align3] read %d forward step %d row %d cell %d L %d o %g e %g prev %g t1 %g\n", rd, u, r, i, sc.L, o, e, prev, t1);
             suspect |= !(o <= HUGE_V);
             prev = o;
             // ---- posterior of the cell, on the scale 2^-K:  post = prefix * suffix
@@ -723,7 +718,6 @@ int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadM
     g.c_cap = cls[k].hi;
     g.flag_above = (k == ncls - 1) ? 1 : 0;
     g.rsh = rsh;
-    g.debug = getenv("NADAVCA_ALIGN_DEBUG") ? 1 : 0;
     g.n_retry = d_retry;
     g.out_events = out_events;
     g.out_status = out_status;
