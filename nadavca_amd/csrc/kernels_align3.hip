@@ -170,7 +170,9 @@ struct Scale {
   int d_next;   // shift of the NEXT step (densities are computed one step ahead)
 };
 
-template <int MEL>
+// RSHC: log2 of the rescale period as a compile-time constant (the usual launch), 0: taken from the
+// launch arguments (wide-band launch)
+template <int MEL, int RSHC>
 __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double *etab = reinterpret_cast<double *>(smem);
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
     int K = 0;          // true exponent of the largest suffix[0][.]
     bool suspect = false;  // something left the double range: the exact kernel must redo this read
     const int sA0 = ((-c - MEL) % H + H) % H, sB0 = ((-c) % H + H) % H;
-    const int RSH = g.rsh, RS = 1 << RSH;
+    const int RSH = RSHC ? RSHC : g.rsh, RS = 1 << RSH;
 
     // =========================== reverse sweep: suffix rows -> spill ===========================
     {
@@ -643,13 +645,14 @@ int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadM
   int *d_retry = counter + 2;
   NVK_HIP(hipMemsetAsync(counter, 0, 4 * sizeof(int), ctx->stream));
 
-  void (*kern)(Align3Args) = nullptr;
+  void (*kern16)(Align3Args) = nullptr;  // rescale period 16 compiled in
+  void (*kernv)(Align3Args) = nullptr;   // period from the arguments
   switch (mel) {
-    case 0: kern = align3_kernel<0>; break;
-    case 1: kern = align3_kernel<1>; break;
-    case 2: kern = align3_kernel<2>; break;
-    case 3: kern = align3_kernel<3>; break;
-    default: kern = align3_kernel<4>; break;
+    case 0: kern16 = align3_kernel<0, 4>; kernv = align3_kernel<0, 0>; break;
+    case 1: kern16 = align3_kernel<1, 4>; kernv = align3_kernel<1, 0>; break;
+    case 2: kern16 = align3_kernel<2, 4>; kernv = align3_kernel<2, 0>; break;
+    case 3: kern16 = align3_kernel<3, 4>; kernv = align3_kernel<3, 0>; break;
+    default: kern16 = align3_kernel<4, 4>; kernv = align3_kernel<4, 0>; break;
   }
   {
     TimerScope ts(ctx, NVK_K_PLAN);
@@ -721,6 +724,7 @@ int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadM
     g.n_retry = d_retry;
     g.out_events = out_events;
     g.out_status = out_status;
+    void (*kern)(Align3Args) = (rsh == 4) ? kern16 : kernv;
     if (lds > 64 * 1024)
       NVK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     {
