@@ -150,3 +150,32 @@ print("ELL-EXACT-OK")
     env = dict(os.environ, NADAVCA_ELL_KERNEL='1')
     p = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and 'ELL-EXACT-OK' in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+
+
+@pytest.mark.parametrize('k,central', [(7, 3), (4, 0), (2, 1)])
+def test_ell_other_kmer_sizes(dtw, oracle_port, k, central):
+    """k-mer sizes other than the packaged 6: k = 7 does not fit the default hypothesis phase's lane
+    layout (k + 2 lanes of 8) and is served by the original one; small k and off-centre k-mers move the
+    range of rows a substitution touches."""
+    from nadavca_amd import synthetic
+    model = synthetic.synth_model_arrays(31 + k, k=k, central=central)
+    mg = dtw.KmerModel(*model)
+    mo = oracle_port.KmerModel(*model)
+    cases = []
+    for i in range(6):
+        rng = np.random.default_rng([89, k, i])
+        R = int(rng.integers(4, 70))
+        cases.append(synthetic.make_dp_case(rng, model, R=R, bandwidth=int(rng.integers(10, 40)), dwell=(2, 9), jitter=5,
+                                            anchor_density=float(rng.uniform(0.2, 0.9)), with_context=bool(i % 2),
+                                            trim=min(3, R // 3)))
+    for w in (False, True):
+        got = dtw.estimate_log_likelihoods_batch(_reads(cases), 30, 2, mg, w)
+        for c_, ll in zip(cases, got):
+            exp = oracle_port.estimate_log_likelihoods(c_['signal'], c_['reference'], c_['context_before'],
+                                                       c_['context_after'], c_['approximate_alignment'], 30, 2, mo, w)
+            _close(ll, exp)
+    got = dtw.refine_alignment_batch(_reads(cases), 30, 2, mg, True)
+    for c_, ev in zip(cases, got):
+        exp = oracle_port.refine_alignment(c_['signal'], c_['reference'], c_['context_before'], c_['context_after'],
+                                           c_['approximate_alignment'], 30, 2, mo, True)
+        assert np.array_equal(ev, exp)
