@@ -179,3 +179,26 @@ def test_ell_other_kmer_sizes(dtw, oracle_port, k, central):
         exp = oracle_port.refine_alignment(c_['signal'], c_['reference'], c_['context_before'], c_['context_after'],
                                            c_['approximate_alignment'], 30, 2, mo, True)
         assert np.array_equal(ev, exp)
+
+
+@pytest.mark.parametrize('alphabet', [3, 5])
+def test_ell_other_alphabet_sizes(dtw, oracle_port, alphabet):
+    """The substitution hypotheses run over alphabet - 1 bases per position; the reference's
+    KmerModel takes the alphabet size as a parameter (kmer_model.cpp:6-14)."""
+    from nadavca_amd import synthetic
+    model = synthetic.synth_model_arrays(41 + alphabet, k=4, central=1, alphabet=alphabet)
+    mg = dtw.KmerModel(*model)
+    mo = oracle_port.KmerModel(*model)
+    cases = []
+    for i in range(5):
+        rng = np.random.default_rng([90, alphabet, i])
+        R = int(rng.integers(5, 60))
+        cases.append(synthetic.make_dp_case(rng, model, R=R, bandwidth=25, dwell=(2, 8), jitter=4,
+                                            anchor_density=0.6, with_context=bool(i % 2), trim=min(3, R // 3)))
+    for w in (False, True):
+        got = dtw.estimate_log_likelihoods_batch(_reads(cases), 25, 2, mg, w)
+        for c_, ll in zip(cases, got):
+            assert ll.shape == (len(c_['reference']), alphabet)
+            exp = oracle_port.estimate_log_likelihoods(c_['signal'], c_['reference'], c_['context_before'],
+                                                       c_['context_after'], c_['approximate_alignment'], 25, 2, mo, w)
+            _close(ll, np.asarray(exp))
