@@ -67,10 +67,10 @@ def cpu_baseline(batch, model, bandwidth, mel, workload, budget_reads_per_core=2
             'per_core': n / dt / cores}
 
 
-def measured_traffic(workload, n_reads):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/*_hbm_traffic.json; counters cannot be read from inside this process).  None when no
-    measurement exists for this workload/size."""
+def measured_traffic(workload, n_reads, key='bytes_per_launch'):
+    """HBM bytes per launch of the dominant kernel (or another recorded figure, `key`) from the
+    committed rocprofv3 PMC passes (profiles/*_hbm_traffic.json; counters cannot be read from inside
+    this process).  None when no measurement exists for this workload/size."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_hbm_traffic.json')), reverse=True):
         try:
@@ -78,7 +78,7 @@ def measured_traffic(workload, n_reads):
         except Exception:
             continue
         if t.get('workload') == workload and int(t.get('reads_per_launch', -1)) == int(n_reads):
-            return t['bytes_per_launch']
+            return t.get(key)
     return None
 
 
@@ -184,6 +184,9 @@ def main():
             out['roofline'] = {'bound': 'hbm', 'kernel': kname, 'achieved': ach, 'peak': HBM_PEAK_GBS,
                                'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
                                'traffic': measured_traffic(args.workload, n_reads),
+                               # what actually limits the kernel: share of cycles its SIMDs issue
+                               # vector instructions (same PMC passes)
+                               'valu_busy': measured_traffic(args.workload, n_reads, 'valu_busy_frac'),
                                'algorithmic_bytes_per_launch': algo, 'kernel_ms_per_launch': ms / launches,
                                'all_kernels_ms': {k: v[0] / max(v[1], 1) for k, v in timing.items() if v[1]}}
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only (contract)
