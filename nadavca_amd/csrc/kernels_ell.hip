@@ -414,11 +414,10 @@ __device__ void sweep_fast(const FusedParam *desc, int R, int N, int c, const do
       while (r_old < R && __builtin_amdgcn_readlane(j, r_old & 63) != r_old) r_old++;
     }
     if (r_old < R) fill(t - c * r_old);
-    if ((u & (HRS - 1)) == HRS - 1) {  // keep the lazily summed mantissas near 1
+    if ((u & (HRS - 1)) == HRS - 1) {  // keep the lazily summed mantissas of the wobble row near 1
       asm volatile("");
 #pragma unroll
       for (int k = 0; k <= MEL; k++) st.wq[k] = xm::norm(st.wq[k]);
-      st.em = xm::norm(st.em);
     }
     const double x = ring[(i - 1) & RM];
     const int hs = sr * 64 + ((lane - 1) & 63);
@@ -428,7 +427,13 @@ __device__ void sweep_fast(const FusedParam *desc, int R, int N, int c, const do
     const X ga{hist_g[hs], hist_e[2 * hs + 1]};
     if (j == 0) pred = xm::one();  // prefix[0] / suffix[R]: all ones on their band
     const X gb = density_x(x, d.bm, d.bac, d.bmc, etab);
-    const X en = fused_step_fast<MEL>(d, st, i, gb, ga, pred);
+    // The emitting value is handed from lane to lane R times: it is normalised on EVERY step.  A value
+    // that dominates the sums it enters passes its mantissa on, so any systematic factor per hand-over
+    // (the 0.5 of xm::one() with mel = 0, the emission product's mantissa otherwise) would compound to
+    // 2^-R or 2^+R along the lanes, whatever the lanes do to their own registers in between.
+    (void)fused_step_fast<MEL>(d, st, i, gb, ga, pred);
+    st.em = xm::norm(st.em);
+    const X en = st.em;
     const int hw = su * 64 + lane;
     hist_m[hw] = en.m;
     hist_g[hw] = gb.m;
