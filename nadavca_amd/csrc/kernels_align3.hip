@@ -43,10 +43,12 @@ constexpr int PF = 4;       // forward sweep: spill prefetch depth (steps)
 // rescale period: 2^rsh steps (launch parameter, >= 16); must exceed c + mel so that at most one
 // rescale lies inside the window a neighbour value travels through
 constexpr int GBIG = 1 << 24;  // scale of an empty running maximum (see the path step)
-// largest upward move per rescale: when only off-path cells are live (the last rows at the end of a
-// sweep) the wave's largest value can collapse by more than the double range within one period; those
-// values are negligible, so they are allowed to flush instead of dragging the scale (and the next
-// densities' exponents) out of range
+// Largest upward move per rescale.  When the wave's largest value collapses by more than this within one
+// period (only off-path cells live, or a sharp model on a noisy signal) the running scale cannot follow
+// without sending the next densities' exponents out of range; the move is capped (no inf / NaN is ever
+// produced) and the read is handed to the exact kernel — capping silently was tried and is WRONG: the
+// values that flush then can decide the path search although every row sum still checks out
+// (tools/fuzz_parity.py seed 11, iteration 4230).
 constexpr int DMAX = 512;
 constexpr int TARGET = 250; // exponent the largest live value is moved to
 #define HUGE_V 0x1.0p+900
@@ -348,6 +350,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
           int ex = (o != 0.0) ? __builtin_amdgcn_frexp_exp(o) : -0x40000000;
           int mx = wave_max_i(ex);
           sc.d_next = (mx > -0x40000000) ? min(TARGET - mx, DMAX) : 0;
+          suspect |= (mx > -0x40000000) && (TARGET - mx > DMAX);
         }
         i -= 1;
         e3 = e2; e2 = e1; e1 = e;
@@ -549,6 +552,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
               int ex = (o != 0.0) ? __builtin_amdgcn_frexp_exp(o) : -0x40000000;
               int mx = wave_max_i(ex);
               sc.d_next = (mx > -0x40000000) ? min(TARGET - mx, DMAX) : 0;
+          suspect |= (mx > -0x40000000) && (TARGET - mx > DMAX);
             }
             i += 1;
             e3 = e2; e2 = e1; e1 = e;

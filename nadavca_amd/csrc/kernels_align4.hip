@@ -391,6 +391,7 @@ __device__ __forceinline__ void sweep(const Half &h, int maxsteps, double *ring,
           if (b != 0.0) ex = max(ex, __builtin_amdgcn_frexp_exp(b));
           ex = half_max_i(ex);
           d_next = (ex > -EBIG) ? min(TARGET - ex, DMAX) : 0;
+          suspect |= (ex > -EBIG) && (TARGET - ex > DMAX);  // see kernels_align3.hip
         }
         i += 1;
         e3 = e2; e2 = e1; e1 = e;

@@ -155,3 +155,43 @@ class OracleKmerModel:
             self.oracle._destroy(self.handle)
         except Exception:
             pass
+
+
+LD_LIB = os.path.join(_HERE, "liboracle_ld.so")
+
+
+class LongDoubleReferee:
+    """refine_alignment of the C restatement compiled with every ``double`` an 80-bit ``long double``
+    (``make -C oracle liboracle_ld.so``).  Used where the engine and the double-precision reference
+    disagree on a row: the reference decides such rows by the rounding of its log-domain doubles
+    (DESIGN.md 2.1); the same algorithm with 11 more mantissa bits says which answer the mathematics
+    supports."""
+
+    def __init__(self, k, central_position, alphabet_size, mean, sigma):
+        if not os.path.isfile(LD_LIB):
+            subprocess.run(["make", "-C", _HERE, "liboracle_ld.so"], check=True, capture_output=True)
+        self.lib = C.CDLL(LD_LIB)
+        self._pld = C.POINTER(C.c_longdouble)
+        self.lib.orc_model_create.restype = C.c_void_p
+        self.lib.orc_model_create.argtypes = [C.c_int, C.c_int, C.c_int, self._pld, self._pld, C.c_int64]
+        self.lib.orc_refine_alignment.restype = C.c_int
+        self.lib.orc_refine_alignment.argtypes = [C.c_void_p, self._pld, C.c_int64, _p_i32, C.c_int64, _p_i32,
+                                                  C.c_int64, _p_i32, C.c_int64, _p_i32, C.c_int64, C.c_int,
+                                                  C.c_int, C.c_int, _p_i32]
+        mean = np.ascontiguousarray(mean, dtype=np.longdouble)
+        sigma = np.ascontiguousarray(sigma, dtype=np.longdouble)
+        self.handle = self.lib.orc_model_create(int(k), int(central_position), int(alphabet_size),
+                                                mean.ctypes.data_as(self._pld), sigma.ctypes.data_as(self._pld),
+                                                mean.size)
+
+    def refine_alignment(self, signal, reference, context_before, context_after, approximate_alignment,
+                         bandwidth, min_event_length, model_transitions):
+        sig = np.ascontiguousarray(signal, dtype=np.longdouble)
+        ref, cb, ca, anc = _i32(reference), _i32(context_before), _i32(context_after), _i32(approximate_alignment)
+        out = np.zeros((ref.size, 2), dtype=np.int32)
+        st = self.lib.orc_refine_alignment(self.handle, sig.ctypes.data_as(self._pld), sig.size,
+                                           ref.ctypes.data_as(_p_i32), ref.size, cb.ctypes.data_as(_p_i32), cb.size,
+                                           ca.ctypes.data_as(_p_i32), ca.size, anc.ctypes.data_as(_p_i32),
+                                           anc.size // 2, int(bandwidth), int(min_event_length),
+                                           int(bool(model_transitions)), out.ctypes.data_as(_p_i32))
+        return out if st == 0 else np.zeros((0, 2), dtype=np.int32)

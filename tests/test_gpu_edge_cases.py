@@ -122,3 +122,45 @@ def test_mixed_narrow_and_wide_reads_in_one_batch(dtw, oracle_port):
             exp = oracle_port.refine_alignment(c['signal'], c['reference'], c['context_before'], c['context_after'],
                                                c['approximate_alignment'], 400, 2, mo, tr)
             assert np.array_equal(ev, exp)
+
+
+def _fuzz_batch(seed, it):
+    from fuzz_cases import make_fuzz_batch, reads_of
+    fb = make_fuzz_batch(seed, it)
+    return fb, reads_of(fb['cases'])
+
+
+def test_sharp_model_collapse_goes_to_the_exact_kernel(dtw, oracle_port):
+    """tools/fuzz_parity.py seed 11, iteration 4230: a model three times sharper than the signal's noise.
+    The wave's largest value collapses by more than the running scale can follow; capping the scale
+    silently produced a different path while every row-mass check passed.  The read must come out as the
+    reference has it (it is handed to the exact kernel)."""
+    fb, reads = _fuzz_batch(11, 4230)
+    mg = dtw.KmerModel(*fb['model'])
+    mo = oracle_port.KmerModel(*fb['model'])
+    got = dtw.refine_alignment_batch(reads, fb['bw'], fb['mel'], mg, fb['tr'])
+    for c, ev in zip(fb['cases'], got):
+        exp = oracle_port.refine_alignment(c['signal'], c['reference'], c['context_before'], c['context_after'],
+                                           c['approximate_alignment'], fb['bw'], fb['mel'], mo, fb['tr'])
+        assert np.array_equal(ev, exp)
+
+
+@pytest.mark.parametrize('seed,it,case,rows', [(7, 448, 7, [140]), (7, 2897, 6, [33]), (1, 694, 2, [11, 136])])
+def test_differences_from_the_reference_are_its_own_rounding(dtw, oracle_port, seed, it, case, rows):
+    """Rows on which this engine and the double-precision reference disagree although no two adjacent
+    k-mers are equal: the reference's log-sum-exp absorbs terms at |L| ~ 1e4, and the SAME
+    algorithm evaluated in long double (oracle/liboracle_ld.so) gives this engine's answer."""
+    from oracle.oracle import LongDoubleReferee
+    fb, reads = _fuzz_batch(seed, it)
+    mg = dtw.KmerModel(*fb['model'])
+    mo = oracle_port.KmerModel(*fb['model'])
+    c = fb['cases'][case]
+    got = dtw.refine_alignment_batch(reads, fb['bw'], fb['mel'], mg, fb['tr'])[case]
+    ref = oracle_port.refine_alignment(c['signal'], c['reference'], c['context_before'], c['context_after'],
+                                       c['approximate_alignment'], fb['bw'], fb['mel'], mo, fb['tr'])
+    hp = LongDoubleReferee(*fb['model']).refine_alignment(c['signal'], c['reference'], c['context_before'],
+                                                          c['context_after'], c['approximate_alignment'], fb['bw'],
+                                                          fb['mel'], fb['tr'])
+    for r in rows:
+        assert not np.array_equal(ref[r], hp[r])      # the reference's own precision decides this row
+        assert np.array_equal(got[r], hp[r])          # and the extended-precision answer is the engine's

@@ -2,30 +2,17 @@
 usage: fuzz_repro.py SEED IT [ell|align]"""
 import sys, os
 import numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 from nadavca_amd import dtw, synthetic
 from oracle.oracle import Oracle
+from fuzz_cases import make_fuzz_batch, reads_of
 seed0, it = int(sys.argv[1]), int(sys.argv[2])
 what = sys.argv[3] if len(sys.argv) > 3 else 'both'
 o = Oracle('port')
-rng = np.random.default_rng([seed0, it])
-k = int(rng.integers(2, 7)); central = int(rng.integers(0, k))
-alphabet = int(rng.choice([4, 4, 4, 3, 5]))
-model = synthetic.synth_model_arrays(int(rng.integers(1 << 30)), k=k, central=central, alphabet=alphabet)
-if rng.random() < 0.3:
-    model = model[:4] + (model[4] * float(rng.choice([0.3, 3.0])),)
+fb = make_fuzz_batch(seed0, it)
+model, k, central, alphabet, mel, bw, cases, tr, w = (fb[x] for x in ('model', 'k', 'central', 'alphabet', 'mel', 'bw', 'cases', 'tr', 'w'))
 mg = dtw.KmerModel(*model); mo = o.KmerModel(*model)
-mel = int(rng.integers(0, 5)); bw = int(rng.integers(4, 90))
-cases = []
-for i in range(int(rng.integers(1, 10))):
-    R = int(rng.integers(1, 260))
-    cases.append(synthetic.make_dp_case(rng, model, R=R, bandwidth=int(rng.integers(4, 90)),
-                                        dwell=(max(mel, 1), int(rng.integers(max(mel, 1) + 1, 14))),
-                                        noise=float(rng.choice([0.1, 0.35, 1.0])), jitter=int(rng.integers(0, 25)),
-                                        anchor_density=float(rng.uniform(0.05, 1.0)), with_context=bool(rng.integers(2)),
-                                        trim=min(3, R // 3)))
-reads = [(c['signal'], c['reference'], c['context_before'], c['context_after'], c['approximate_alignment']) for c in cases]
-tr, w = bool(rng.integers(2)), bool(rng.integers(2))
+reads = reads_of(cases)
 print('k', k, 'central', central, 'alphabet', alphabet, 'sigma', model[4][0], 'mel', mel, 'bw', bw, 'tr', tr, 'w', w, 'reads', len(cases),
       'variant', os.environ.get('NADAVCA_ALIGN_KERNEL'), os.environ.get('NADAVCA_ELL_KERNEL'))
 if what in ('both', 'align'):
