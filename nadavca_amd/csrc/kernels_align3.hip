@@ -49,7 +49,7 @@ constexpr int GBIG = 1 << 24;  // scale of an empty running maximum (see the pat
 // produced) and the read is handed to the exact kernel — capping silently was tried and is WRONG: the
 // values that flush then can decide the path search although every row sum still checks out
 // (tools/fuzz_parity.py seed 11, iteration 4230).
-constexpr int DMAX = 512;
+constexpr int DMAX = 900;  // the density exponent (<= ~3) plus the move must stay inside the double range
 constexpr int TARGET = 250; // exponent the largest live value is moved to
 #define HUGE_V 0x1.0p+900
 #define MASS_TOL 1e-9          // allowed relative spread of the rows' posterior mass
@@ -167,8 +167,7 @@ __device__ __forceinline__ int wave_max_i(int v) {  // result in a scalar regist
 // running scale: L(u) = L(u-1) + delta_u; delta is nonzero only on rescale steps
 struct Scale {
   int L;        // current log-scale
-  int u_last;   // step of the last rescale
-  int d_last;   // its shift
+  int d_last;   // shift applied at the last rescale step (every RS steps; may be 0)
   int d_next;   // shift of the NEXT step (densities are computed one step ahead)
 };
 
@@ -257,7 +256,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
         }
       }
       __syncthreads();
-      Scale sc{0, -0x40000000, 0, 0};
+      Scale sc{0, 0, 0};
       double e = density(ring[i & RM], mean, ac2, mc2, 0, etab);
       int su = 0, sA = sA0, sB = sB0;
       bool init_live = true;  // (uniform) the last row is still being swept
@@ -265,9 +264,9 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
       for (int u = 0; u < n_steps; ++u) {
         const int t = t_max - u;
         // this step's shift was decided at the end of the previous one
-        if (sc.d_next != 0) {
+        const int age = u & (RS - 1);  // steps since the last rescale step (the scale only moves there)
+        if (age == 0 && u > 0) {
           sc.L += sc.d_next;
-          sc.u_last = u;
           sc.d_last = sc.d_next;
           sc.d_next = 0;
         }
@@ -281,7 +280,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
               TAKE_LANE(nx);
               hi = nx.end;
               is_init = false;
-              e = density(ring[i & RM], mean, ac2, mc2, (sc.u_last == u) ? sc.d_last : 0, etab);
+              e = density(ring[i & RM], mean, ac2, mc2, (age == 0 && u > 0) ? sc.d_last : 0, etab);
             } else {
               hi = -0x40000000; bs = -0x40000000;
             }
@@ -310,9 +309,8 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
         const double xn = ring[(i - 1) & RM];
         double pv = hist[hs];
         // scalar shifts that bring a neighbour value from D steps ago to the current scale
-        const int age = u - sc.u_last;
-        const int shT = (age < c) ? sc.d_last : 0;                       // D = c      (mel 0 rows)
-        const int shE = (age >= MEL && age < c + MEL) ? sc.d_last : 0;  // D = c+MEL  (beyond the densities' own shifts)
+        // a rescale lies between the step a neighbour value was produced at and now?  (rare, uniform)
+        const bool sh_any = (age < c + MEL) && (u >= RS) && (sc.d_last != 0);
         const DensHalf dn = density_begin(xn, mean, ac2, mc2, etab);
         // ---- the cell (r, i): out = P * pred[i + mel] + e(s[i]) * out[i + 1]
         const bool active = (i <= hi) && (i >= bs);
@@ -321,7 +319,8 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
         const int j = i + melr;
         pv = (j >= pbs && j <= pbe) ? pv : 0.0;
         double t1 = P * pv;
-        if ((shT | shE) != 0) {  // uniform and rare: keep it a branch
+        if (sh_any) {  // D = c for mel 0 rows; D = c + MEL otherwise, beyond the densities' own shifts
+          const int shT = (age < c) ? sc.d_last : 0, shE = (age >= MEL) ? sc.d_last : 0;
           asm volatile("");
           t1 = ldexp(t1, melr == 0 ? shT : shE);
         }
@@ -342,11 +341,11 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
         }
         hist[su * 64 + lane] = o;
         spill_v[(size_t)(t - t_min) * 64 + lane] = o;
-        if ((u & (RS - 1)) == 0) {  // the scale only moves on these steps
+        if (age == 0) {  // the scale only moves on these steps
           if (lane == 0) spill_L[u >> RSH] = sc.L;
         }
         // ---- rescale decision for the next step, then the next step's density
-        if (((u + 1) % RS) == 0) {
+        if (age == RS - 1) {
           int ex = (o != 0.0) ? __builtin_amdgcn_frexp_exp(o) : -0x40000000;
           int mx = wave_max_i(ex);
           sc.d_next = (mx > -0x40000000) ? min(TARGET - mx, DMAX) : 0;
@@ -407,7 +406,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
         filled_hi += CH;
       }
       __syncthreads();
-      Scale sc{0, -0x40000000, 0, 0};
+      Scale sc{0, 0, 0};
       double e = density(ring[(i - 1) & RM], mean, ac2, mc2, 0, etab);
       int su = 0, sA = sA0, sB = sB0;
       bool init_live = true;  // (uniform) row 0 is still being swept
@@ -429,9 +428,9 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
           const int u = ub + q;
           if (u < n_steps) {
             const int t = t_min + u;
-            if (sc.d_next != 0) {
+            const int age = u & (RS - 1);
+            if (age == 0 && u > 0) {
               sc.L += sc.d_next;
-              sc.u_last = u;
               sc.d_last = sc.d_next;
               sc.d_next = 0;
             }
@@ -449,7 +448,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
                   TAKE_LANE(nx);
                   be = nx.end; lo = nx.lo;
                   is_init = false;
-                  e = density(ring[(i - 1) & RM], mean, ac2, mc2, (sc.u_last == u) ? sc.d_last : 0, etab);
+                  e = density(ring[(i - 1) & RM], mean, ac2, mc2, (age == 0 && u > 0) ? sc.d_last : 0, etab);
                 } else {
                   lo = 0x40000000; be = 0x40000000;
                 }
@@ -476,9 +475,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
             const double xn = ring[i & RM];
             const double2 hv = hist2[hs];
             const int Gin = ghist[hs];
-            const int age = u - sc.u_last;
-            const int shT = (age < c) ? sc.d_last : 0;
-            const int shE = (age >= MEL && age < c + MEL) ? sc.d_last : 0;
+            const bool sh_any = (age < c + MEL) && (u >= RS) && (sc.d_last != 0);
             const DensHalf dn = density_begin(xn, mean, ac2, mc2, etab);
             // ---- the cell (r, i): out = P * pred[i - mel] + e(s[i-1]) * out[i - 1]
             const bool active = (i >= lo) && (i <= be);
@@ -491,7 +488,8 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
             pv = ok ? pv : 0.0;
             dv = ok ? dv : 0.0;
             double t1 = P * pv;
-            if ((shT | shE) != 0) {  // uniform and rare: keep it a branch
+            if (sh_any) {  // D = c for mel 0 rows; D = c + MEL otherwise, beyond the densities' own shifts
+          const int shT = (age < c) ? sc.d_last : 0, shE = (age >= MEL) ? sc.d_last : 0;
               asm volatile("");
               t1 = ldexp(t1, melr == 0 ? shT : shE);
             }
@@ -548,7 +546,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
             // refill the prefetch slot just consumed
             cur_v[q] = spill_v[(size_t)(u + PF) * 64 + lane];
             // ---- rescale decision for the next step, then the next step's density
-            if (((u + 1) % RS) == 0) {
+            if (age == RS - 1) {
               int ex = (o != 0.0) ? __builtin_amdgcn_frexp_exp(o) : -0x40000000;
               int mx = wave_max_i(ex);
               sc.d_next = (mx > -0x40000000) ? min(TARGET - mx, DMAX) : 0;

@@ -55,7 +55,7 @@ constexpr int PF = 4;       // forward sweep: spill prefetch depth (steps)
 constexpr int RSH = 4;
 constexpr int RS = 1 << RSH;  // rescale period (steps); must exceed c + mel
 constexpr int TARGET = 250;   // exponent the largest live value of a half is moved to
-constexpr int DMAX = 512;     // largest upward move per rescale (see kernels_align3.hip)
+constexpr int DMAX = 900;     // largest upward move per rescale (see kernels_align3.hip)
 constexpr int GBIG = 1 << 24; // scale of an empty running maximum
 constexpr int EBIG = 0x40000000;
 constexpr int C_CAP4 = 5;     // widest skew this kernel's rings are sized for (32 lanes per read)
