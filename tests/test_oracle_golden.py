@@ -89,3 +89,22 @@ def test_port_bit_identical_to_compiled_reference_when_present(oracle_port):
             x = oracle_port.estimate_log_likelihoods(*a, mp, flag)
             y = ref.estimate_log_likelihoods(*a, mr, flag)
             assert np.array_equal(x, y)
+
+
+def test_long_double_referee_builds_and_disagrees_where_pinned():
+    """oracle/liboracle_ld.so (the restatement in 80-bit long double) is the referee for rows the engine
+    and the double reference disagree on; on the pinned fuzz cases the double and long-double results
+    must differ exactly on the pinned rows (CPU only; the engine's side is checked in the GPU tests)."""
+    import numpy as np
+    from fuzz_cases import make_fuzz_batch
+    from oracle.oracle import Oracle, LongDoubleReferee
+    o = Oracle('port')
+    for seed, it, case, rows in [(7, 448, 7, [140]), (7, 2897, 6, [33]), (1, 694, 2, [11, 115, 116, 136])]:
+        fb = make_fuzz_batch(seed, it)
+        c = fb['cases'][case]
+        mo = o.KmerModel(*fb['model'])
+        a = (c['signal'], c['reference'], c['context_before'], c['context_after'], c['approximate_alignment'],
+             fb['bw'], fb['mel'])
+        dbl = o.refine_alignment(*a, mo, fb['tr'])
+        ld = LongDoubleReferee(*fb['model']).refine_alignment(*a, fb['tr'])
+        assert np.nonzero((dbl != ld).any(axis=1))[0].tolist() == rows
