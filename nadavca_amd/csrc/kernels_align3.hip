@@ -676,7 +676,11 @@ int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadM
   if (max_c > ALIGN1_C_CAP) cls[ncls++] = Cls{ALIGN1_C_CAP, max_c < C_HARD ? max_c : C_HARD, n_wide};
   for (int k = 0; k < ncls; k++) {
     const int c = cls[k].hi;
-    int rsh = 4;
+    // Rescale period 16, or 8 without transition rows: there the last rows of a sweep run through
+    // far-off-path cells with nothing slower beside them (the constant-density rows), the wave's
+    // largest value collapses ~70 bits per step, and a period of 16 steps overruns the scale-move cap
+    // on 1-2 % of the reads (each such read costs a pass of the exact kernel).
+    int rsh = transitions ? 4 : 3;
     while ((1 << rsh) <= c + mel + 1) rsh++;
     // history ring: ages 1 .. c+mel are read; the oldest slot is read and then overwritten in the
     // same step (LDS operations of one wave execute in program order)
