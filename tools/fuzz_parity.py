@@ -12,6 +12,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 o = Oracle('port')
 t_end = time.time() + budget
+t_tick = time.time() + 60
 n_batches = n_reads = n_bad = n_tie = n_hp = n_ill = 0
 it = 0
 while time.time() < t_end:
@@ -20,6 +21,9 @@ while time.time() < t_end:
     mg = dtw.KmerModel(*model); mo = o.KmerModel(*model); ld = None
     reads = reads_of(cases)
     n_batches += 1; n_reads += len(cases)
+    if time.time() > t_tick:
+        t_tick = time.time() + 60
+        print('... %d batches, %d reads, %d differ, %d unexplained' % (n_batches, n_reads, n_bad, n_bad - n_tie), file=sys.stderr, flush=True)
     got = dtw.refine_alignment_batch(reads, bw, mel, mg, tr)
     for ci, (c, ev) in enumerate(zip(cases, got)):
         exp = np.asarray(o.refine_alignment(c['signal'], c['reference'], c['context_before'], c['context_after'],
