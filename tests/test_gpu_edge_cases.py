@@ -164,3 +164,22 @@ def test_differences_from_the_reference_are_its_own_rounding(dtw, oracle_port, s
     for r in rows:
         assert not np.array_equal(ref[r], hp[r])      # the reference's own precision decides this row
         assert np.array_equal(got[r], hp[r])          # and the extended-precision answer is the engine's
+
+
+def test_ell_long_read_wide_band(dtw, oracle_port):
+    """SNP log-likelihoods on a 900-base read with bandwidth 400: more than 14 lane hand-overs per lane
+    in the sweeps (the fast sweeps once compounded mantissas along the lanes) and a descriptor window
+    that wraps many times."""
+    from nadavca_amd import synthetic
+    model = synthetic.load_model_arrays()
+    mg = dtw.KmerModel(*model)
+    mo = oracle_port.KmerModel(*model)
+    rng = np.random.default_rng(4242)
+    c = synthetic.make_dp_case(rng, model, R=900, bandwidth=400, jitter=40, anchor_density=0.5)
+    a = (c['signal'], c['reference'], c['context_before'], c['context_after'], c['approximate_alignment'], 400, 2)
+    for w in (True, False):
+        got = np.asarray(dtw.estimate_log_likelihoods(*a, mg, w))
+        exp = np.asarray(oracle_port.estimate_log_likelihoods(*a, mo, w))
+        assert np.array_equal(np.isneginf(got), np.isneginf(exp)) and not np.any(np.isnan(got))
+        fin = np.isfinite(exp)
+        assert np.allclose(got[fin], exp[fin], rtol=1e-9, atol=1e-9)
