@@ -88,6 +88,7 @@ struct Align3Args {
   int64_t bp_stride;     // words per slot
   int n_reads;
   int *counter;
+  const int *order;  // reads in the order they are handed out (longest first), or null
   int H, SR;
   int transitions;
   int c_lo, c_cap;  // this launch serves reads with c_lo < c <= c_cap
@@ -196,8 +197,9 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
     __syncthreads();
     if (lane == 0) *s_read = atomicAdd(g.counter, 1);
     __syncthreads();
-    const int rd = __builtin_amdgcn_readfirstlane(*s_read);
-    if (rd >= g.n_reads) break;
+    const int pos = __builtin_amdgcn_readfirstlane(*s_read);
+    if (pos >= g.n_reads) break;
+    const int rd = g.order ? g.order[pos] : pos;
     const ReadMeta m = g.metas[rd];
     if (m.status != NVK_READ_OK) {
       if (lane == 0) g.out_status[rd] = m.status;
@@ -662,6 +664,9 @@ int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadM
                        (Lane3 *)ctx->ws[WS_LANE_F], (Lane3 *)ctx->ws[WS_LANE_R], (int)a.n_reads);
   }
   NVK_HIP(hipGetLastError());
+  int *order = nullptr;
+  rc = launch_order(ctx, metas, a.n_reads, max_steps, &order);
+  if (rc) return rc;
 
   // Two launches: the LDS rings are sized by the largest skew a launch serves, so the (usual) reads
   // with c <= ALIGN1_C_CAP keep their 16 waves per CU whatever else is in the batch; wide-band reads
@@ -720,6 +725,7 @@ int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadM
     g.bp_stride = bp_stride;
     g.n_reads = (int)a.n_reads;
     g.counter = counter;
+    g.order = order;
     g.H = H;
     g.SR = SR;
     g.transitions = transitions;

@@ -72,6 +72,7 @@ struct EllArgs {
   int64_t half;          // cells per half
   int n_reads;
   int *counter;
+  const int *order;  // reads in the order they are handed out (longest first), or null
   int H, SR;
   int wobbling;
   double *out_ll;
@@ -481,8 +482,9 @@ __global__ __launch_bounds__(64, 3) void ell_kernel(EllArgs g) {
     __syncthreads();
     if (lane == 0) *s_read = atomicAdd(g.counter, 1);
     __syncthreads();
-    const int rd = __builtin_amdgcn_readfirstlane(*s_read);
-    if (rd >= g.n_reads) break;
+    const int pos = __builtin_amdgcn_readfirstlane(*s_read);
+    if (pos >= g.n_reads) break;
+    const int rd = g.order ? g.order[pos] : pos;
     const ReadMeta m = g.pl.metas[rd];
     const int R = __builtin_amdgcn_readfirstlane(m.R);
     double *out = g.out_ll + (size_t)m.ref_off * alpha;
@@ -840,6 +842,12 @@ int launch_ell(nvk_ctx *ctx, const DeviceModel &dm, const BatchArgs &a, int wobb
   g.half = half;
   g.n_reads = (int)a.n_reads;
   g.counter = counter;
+  {
+    int *order = nullptr;
+    rc = launch_order(ctx, pl.metas, a.n_reads, tot.max_steps, &order);
+    if (rc) return rc;
+    g.order = order;
+  }
   g.H = H;
   g.SR = SR;
   g.wobbling = wobbling;

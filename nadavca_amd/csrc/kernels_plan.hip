@@ -584,7 +584,61 @@ __global__ void expected_kernel(DeviceModel dm, int64_t n_reads, int64_t total_r
   out[g] = dm.mean[id];
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Longest-first work order.  Persistent waves take whole reads from a counter; when read lengths
+// differ, the launch ends with the waves that happened to start a long read last.  Handing the reads
+// out longest first (64 buckets of the step count, descending, original order inside a bucket up
+// to the race of the fill) bounds that tail by the shortest reads instead.
+// ---------------------------------------------------------------------------------------------
+constexpr int ORD_B = 64;
+__device__ __forceinline__ int order_bucket(const ReadMeta &m, int max_steps) {
+  if (m.status != NVK_READ_OK) return ORD_B - 1;
+  long long b = (long long)m.n_steps * ORD_B / ((long long)max_steps + 1);
+  return ORD_B - 1 - (int)(b < 0 ? 0 : (b > ORD_B - 1 ? ORD_B - 1 : b));
+}
+__global__ void order_count_kernel(const ReadMeta *metas, int n, int max_steps, int *cnt) {
+  int rd = blockIdx.x * blockDim.x + threadIdx.x;
+  if (rd < n) atomicAdd(&cnt[order_bucket(metas[rd], max_steps)], 1);
+}
+__global__ void order_scan_kernel(int *cnt) {  // one wave: cnt[b] -> first position of bucket b; cnt[64+b] = 0
+  int lane = threadIdx.x;
+  int v = cnt[lane], s = v;
+  for (int d = 1; d < 64; d <<= 1) {
+    int o = __shfl_up(s, d, 64);
+    if (lane >= d) s += o;
+  }
+  cnt[lane] = s - v;
+  cnt[ORD_B + lane] = 0;
+}
+__global__ void order_fill_kernel(const ReadMeta *metas, int n, int max_steps, int *cnt, int *order) {
+  int rd = blockIdx.x * blockDim.x + threadIdx.x;
+  if (rd < n) {
+    int b = order_bucket(metas[rd], max_steps);
+    order[cnt[b] + atomicAdd(&cnt[ORD_B + b], 1)] = rd;
+  }
+}
+
 }  // namespace
+
+// order[0..n) = read indices, longest (by step count) first; `order` lives in ctx->ws[WS_ORDER]
+int launch_order(nvk_ctx *ctx, const ReadMeta *metas, int64_t n_reads, int max_steps, int **order) {
+  *order = nullptr;
+  if (n_reads <= 0) return NVK_OK;
+  int rc = nvk_ws_reserve(ctx, WS_ORDER, (size_t)n_reads * sizeof(int) + 2 * ORD_B * sizeof(int));
+  if (rc) return rc;
+  int *ord = (int *)ctx->ws[WS_ORDER];
+  int *cnt = ord + n_reads;
+  NVK_HIP(hipMemsetAsync(cnt, 0, 2 * ORD_B * sizeof(int), ctx->stream));
+  const unsigned blocks = (unsigned)((n_reads + 255) / 256);
+  TimerScope ts(ctx, NVK_K_PLAN);
+  hipLaunchKernelGGL(order_count_kernel, dim3(blocks), dim3(256), 0, ctx->stream, metas, (int)n_reads, max_steps, cnt);
+  hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(64), 0, ctx->stream, cnt);
+  hipLaunchKernelGGL(order_fill_kernel, dim3(blocks), dim3(256), 0, ctx->stream, metas, (int)n_reads, max_steps, cnt, ord);
+  NVK_HIP(hipGetLastError());
+  *order = ord;
+  return NVK_OK;
+}
 
 int launch_plan(nvk_ctx *ctx, const DeviceModel &dm, const BatchArgs &a, int mode, int wobbling,
                 ReadMeta *metas, RowParam *rows, unsigned long long *bandtmp, PlanTotals *totals) {

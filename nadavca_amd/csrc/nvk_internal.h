@@ -86,7 +86,7 @@ struct DeviceModel {
 
 // ----- host-side objects ------------------------------------------------------------------
 enum { WS_META = 0, WS_ROWS = 1, WS_BANDTMP = 2, WS_SPILL = 3, WS_BP = 4, WS_MISC = 5, WS_ROWS2 = 6, WS_STAGE = 7,
-       WS_SPILL_B = 8, WS_STAGE_B = 9, WS_BP_B = 10, WS_LANE_F = 11, WS_LANE_R = 12, WS_COUNT = 13 };
+       WS_SPILL_B = 8, WS_STAGE_B = 9, WS_BP_B = 10, WS_LANE_F = 11, WS_LANE_R = 12, WS_ORDER = 13, WS_COUNT = 14 };
 
 struct nvk_ctx {
   int device;
@@ -155,6 +155,7 @@ enum { PLAN_ALIGN_TRANS = 0, PLAN_ALIGN_PLAIN = 1, PLAN_ELL = 2 };
 
 int launch_plan(nvk_ctx *ctx, const DeviceModel &dm, const BatchArgs &a, int mode, int wobbling,
                 ReadMeta *metas, RowParam *rows, unsigned long long *bandtmp, PlanTotals *totals);
+int launch_order(nvk_ctx *ctx, const ReadMeta *metas, int64_t n_reads, int max_steps, int **order);
 int launch_align(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadMeta *metas,
                  const RowParam *rows, const PlanTotals &tot, int32_t *out_events,
                  int32_t *out_status);
