@@ -48,7 +48,7 @@ constexpr int GBIG = 1 << 24;  // scale of an empty running maximum (see the pat
 // without sending the next densities' exponents out of range; the move is capped (no inf / NaN is ever
 // produced) and the read is handed to the exact kernel — capping silently was tried and is WRONG: the
 // values that flush then can decide the path search although every row sum still checks out
-// (tools/fuzz_parity.py seed 11, iteration 4230).
+// (tests/dev/fuzz_parity.py seed 11, iteration 4230).
 constexpr int DMAX = 900;  // the density exponent (<= ~3) plus the move must stay inside the double range
 constexpr int TARGET = 250; // exponent the largest live value is moved to
 #define HUGE_V 0x1.0p+900

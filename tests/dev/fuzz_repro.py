@@ -1,4 +1,4 @@
-"""Re-create iteration IT of tools/fuzz_parity.py (seed SEED) and print the deviations in detail.
+"""Re-create iteration IT of tests/dev/fuzz_parity.py (seed SEED) and print the deviations in detail.
 usage: fuzz_repro.py SEED IT [ell|align]"""
 import sys, os
 import numpy as np

@@ -1,4 +1,4 @@
-"""Seeded random DP problems shared by tools/fuzz_parity.py, tools/fuzz_repro.py and the regression
+"""Seeded random DP problems shared by tests/dev/fuzz_parity.py, tests/dev/fuzz_repro.py and the regression
 tests that pin iterations the fuzzer once failed on."""
 import numpy as np
 

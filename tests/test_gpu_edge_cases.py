@@ -131,7 +131,7 @@ def _fuzz_batch(seed, it):
 
 
 def test_sharp_model_collapse_goes_to_the_exact_kernel(dtw, oracle_port):
-    """tools/fuzz_parity.py seed 11, iteration 4230: a model three times sharper than the signal's noise.
+    """tests/dev/fuzz_parity.py seed 11, iteration 4230: a model three times sharper than the signal's noise.
     The wave's largest value collapses by more than the running scale can follow; capping the scale
     silently produced a different path while every row-mass check passed.  The read must come out as the
     reference has it (it is handed to the exact kernel)."""
