@@ -60,14 +60,16 @@ __device__ __forceinline__ long long wave_sum(long long v) {
 // bands of the R+1 boundary rows (dtw.cpp:7-35): "later anchor overwrites", then
 // prefix-max / suffix-min.  Results are left in the low words of tbs[] / tbe[].
 __device__ void plan_bands(const int32_t *anc, int A, int R, int N, int bw,
-                           unsigned long long *tbs, unsigned long long *tbe, int lane) {
+                           unsigned long long *tbs, unsigned long long *tbe, int lane,
+                           bool work = true) {
+  // `work`: in a multi-wave block one wave does the (wave-scan based) work, every wave takes the barriers
   // scratch word = (anchor ordinal + 1) << 32 | payload ; atomicMax keeps the last anchor
-  for (int j = lane; j <= R; j += 64) {
+  for (int j = lane; work && j <= R; j += 64) {
     tbs[j] = 0ull;
     tbe[j] = 0ull;
   }
   __syncthreads();
-  for (int j = lane; j < A; j += 64) {
+  for (int j = lane; work && j < A; j += 64) {
     int s = anc[2 * j], ri = anc[2 * j + 1];
     long long lo = (long long)s - bw;
     long long hi = (long long)s + bw;
@@ -82,7 +84,7 @@ __device__ void plan_bands(const int32_t *anc, int A, int R, int N, int bw,
   // the row table stores bands as int32 inside RowParam; first write raw per-base bands into
   // the scratch (low words), scanning in chunks of 64 with a carry
   int carry = 0;
-  for (int base = 0; base <= R; base += 64) {
+  for (int base = 0; work && base <= R; base += 64) {
     int j = base + lane;
     int v = 0;
     if (j <= R) {
@@ -94,7 +96,7 @@ __device__ void plan_bands(const int32_t *anc, int A, int R, int N, int bw,
     if (j <= R) tbs[j] = (unsigned long long)(unsigned int)v;
   }
   carry = N;
-  for (int base = (R / 64) * 64; base >= 0; base -= 64) {
+  for (int base = (R / 64) * 64; work && base >= 0; base -= 64) {
     int j = base + lane;
     int v = N;
     if (j <= R) {
@@ -112,13 +114,23 @@ __device__ void plan_bands(const int32_t *anc, int A, int R, int N, int bw,
 }
 
 // bandtmp: per read 2*(R+1) u64 scratch words at bandtmp[2*(ref_off+j) ...]
-__global__ __launch_bounds__(64) void plan_kernel(DeviceModel dm, BatchArgs a, int mode,
+// One block of PLAN_T threads per read: the band scans run on wave 0, the per-row work (k-mer ids,
+// model gathers, row records) on all waves — it is a latency chain of ~13 dependent rounds per lane
+// with 64 threads.
+constexpr int PLAN_T = 256;
+__global__ __launch_bounds__(PLAN_T) void plan_kernel(DeviceModel dm, BatchArgs a, int mode,
                                                   double log_p_in, int c_cap, ReadMeta *metas,
                                                   RowParam *rows, unsigned long long *bandtmp,
                                                   PlanTotals *totals) {
   const int rd = blockIdx.x;
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
+  __shared__ unsigned long long sh_cells;
+  __shared__ int sh_c;
   if (rd >= a.n_reads) return;
+  if (tid == 0) {
+    sh_cells = 0ull;
+    sh_c = 1;
+  }
   const int64_t s0 = a.sig_off[rd], r0 = a.ref_off[rd], a0 = a.anc_off[rd];
   const int64_t N64 = a.sig_off[rd + 1] - s0;
   const int64_t R64 = a.ref_off[rd + 1] - r0;
@@ -155,26 +167,26 @@ __global__ __launch_bounds__(64) void plan_kernel(DeviceModel dm, BatchArgs a, i
 
   int bad = (R < 1 || N < 1 || N64 > 0x3fffffff || R64 > 0x1fffffff) ? 1 : 0;
   // anchors must name an existing band row (reference writes result[reference_index])
-  for (int j = lane; j < A && !bad; j += 64) {
+  for (int j = tid; j < A && !bad; j += PLAN_T) {
     int si = anc[2 * j], ri = anc[2 * j + 1];
     if (ri < 0 || ri > R || si < -(1 << 30) || si > (1 << 30)) bad = 1;
   }
-  bad = __any(bad);
+  bad = __syncthreads_or(bad);
   if (bad) {
     m.status = NVK_READ_BAD_INPUT;
-    if (lane == 0) metas[rd] = m;
+    if (tid == 0) metas[rd] = m;
     return;
   }
 
   unsigned long long *tbs = bandtmp + 2 * (r0 + rd);
   unsigned long long *tbe = tbs + (R + 1);
-  plan_bands(anc, A, R, N, bw, tbs, tbe, lane);
+  plan_bands(anc, A, R, N, bw, tbs, tbe, lane, tid < 64);
 
   // --- row table -----------------------------------------------------------------------------
   RowParam *rp = rows + m.row_off;
   int badband = 0;
   long long cells = 0;
-  for (int r = lane; r < T; r += 64) {
+  for (int r = tid; r < T; r += PLAN_T) {
     RowParam p;
     int bidx = (mode == PLAN_ALIGN_TRANS) ? (r + 1) / 2 : r;
     p.bs = (int)(unsigned int)tbs[bidx];
@@ -207,14 +219,15 @@ __global__ __launch_bounds__(64) void plan_kernel(DeviceModel dm, BatchArgs a, i
     }
     rp[r] = p;
   }
-  badband = __any(badband);
+  badband = __syncthreads_or(badband);
   cells = wave_sum(cells);
+  if (lane == 0) atomicAdd(&sh_cells, (unsigned long long)cells);
   __syncthreads();
 
   // --- occupancy intervals (band + warm-up + pre-roll) and skew ---------------------------------
   // forward lane of row r runs i = lo_r .. be_r, reverse lane i = hi_r .. bs_r  (see kernels_align.hip)
   int cneed = 1;
-  for (int r = lane; r < T; r += 64) {
+  for (int r = tid; r < T; r += PLAN_T) {
     int lo = rp[r].bs, hi = rp[r].be;
     if (r > 0) {
       int pm = rp[r - 1].mel;
@@ -228,14 +241,18 @@ __global__ __launch_bounds__(64) void plan_kernel(DeviceModel dm, BatchArgs a, i
     rp[r].hi = hi;
   }
   __syncthreads();
-  for (int r = 64 + lane; r < T; r += 64) {
+  for (int r = 64 + tid; r < T; r += PLAN_T) {
     int d = rp[r - 64].hi - rp[r].lo;  // need 64*c > d
     if (d >= 0) cneed = max(cneed, d / 64 + 1);
   }
   cneed = max(cneed, max(mel - 1, 1));
-  int c = wave_max(cneed);
+  cneed = wave_max(cneed);
+  if (lane == 0) atomicMax(&sh_c, cneed);
+  __syncthreads();
+  const int c = sh_c;
+  cells = (long long)sh_cells;
 
-  if (lane == 0) {
+  if (tid == 0) {
     int t_min = rp[0].lo;
     int t_max = rp[T - 1].hi + c * (T - 1);
     m.c = c;
@@ -649,7 +666,7 @@ int launch_plan(nvk_ctx *ctx, const DeviceModel &dm, const BatchArgs &a, int mod
     TimerScope ts(ctx, NVK_K_PLAN);
     // the transition constant comes from the host libm, like the model's ac/mc (kmer_model.cpp:77)
     const double log_p_in = log(0.01);
-    hipLaunchKernelGGL(plan_kernel, dim3((unsigned)a.n_reads), dim3(64), 0, ctx->stream, dm, a, mode,
+    hipLaunchKernelGGL(plan_kernel, dim3((unsigned)a.n_reads), dim3(PLAN_T), 0, ctx->stream, dm, a, mode,
                        log_p_in, ALIGN1_C_CAP, metas, rows, bandtmp, totals);
   }
   NVK_HIP(hipGetLastError());
