@@ -819,6 +819,13 @@ int launch_ell(nvk_ctx *ctx, const DeviceModel &dm, const BatchArgs &a, int wobb
   if (per_cu < 1) per_cu = 1;
   int64_t slots = ctx->slots_override > 0 ? ctx->slots_override : (int64_t)ctx->num_cus * per_cu;
   if (slots > a.n_reads) slots = a.n_reads;
+  // This kernel is VALU-bound (80 % busy at 10 waves per CU already), so waves beyond that buy nothing;
+  // what matters is that the persistent waves end together: use no more slots than the number of
+  // rounds needs (10 000 reads: 4 rounds of 2 500 instead of 3.26 rounds of 3 072, measured -2.5 %).
+  if (ctx->slots_override <= 0 && slots > 0) {
+    const int64_t rounds = (a.n_reads + slots - 1) / slots;
+    slots = (a.n_reads + rounds - 1) / rounds;
+  }
   const int64_t half = (int64_t)(tot.max_W > 0 ? tot.max_W : 1) + 64;
   const int64_t stride = 2 * half;
   const int64_t cap = (int64_t)64 << 30;
