@@ -68,12 +68,27 @@ class NadavcaHipError(RuntimeError):
     pass
 
 
+def _torch_runtime_first():
+    """PyTorch-ROCm ships its own copy of the HIP runtime; this library links the system one.  Both can
+    live in one process only if torch's touches the device first — otherwise the first
+    ``tensor.to('cuda')`` after a kernel call of this library fails with "No HIP GPUs are available".
+    So torch's runtime is initialised before this library makes its first HIP call (torch is the
+    package's plumbing for device memory anyway, nadavca_amd/device.py)."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:  # no torch, or no device: this library reports the latter itself
+        pass
+
+
 def load():
     """Load libnadavca_hip.so (once) and attach the prototypes.  Raises if it is missing."""
     global _lib
     with _lock:
         if _lib is not None:
             return _lib
+        _torch_runtime_first()
         if not os.path.isfile(LIB_PATH):
             raise NadavcaHipError(
                 'HIP library not built: %s is missing (run __graft_entry__.build() or '
