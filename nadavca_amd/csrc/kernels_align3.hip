@@ -14,16 +14,25 @@
 //   the shift to the exponent of that step's densities (an integer add on a value that is being
 //   ldexp'ed anyway), and a neighbour value from D steps ago is brought to the current scale by
 //   the (scalar) sum of the shifts of those D steps — zero on most steps, so the ldexp is skipped.
-//   Scaling by powers of two is exact, so as long as nothing leaves the double range the results
-//   are BIT-IDENTICAL to the exact kernel; any under/overflow is detected per read and that read
-//   is re-run by the exact kernel (status NVK_READ_RETRY_INTERNAL, never visible to callers).
+//   Scaling by powers of two is exact, so as long as nothing leaves the double range the integer
+//   results are those of the exact kernel.  Range guards, per read: a value above 2^900 or NaN; a
+//   scale move that had to be capped (the wave's largest value collapsed faster than the scale can
+//   follow); and the ROW MASS — every allowed path crosses every row exactly once, so the posterior
+//   mass sum_i prefix[r][i] * suffix[r][i] is the same number for every row, and a flushed cell
+//   that mattered shows up as a row whose sum deviates.  A flagged read is re-run by the exact
+//   kernel (status NVK_READ_RETRY_INTERNAL, never visible to callers).
 //
 //   Path DP: scores of one row only ever meet scores of the same row (running maximum, arg-max)
-//   or are handed to the next row, so each row carries its own scale: the receiving lane
-//   normalises the running maximum once per row (rho) and passes the accumulated exponent G along
-//   with the score, which is all the tie tolerance of xm::gt_tol needs.
+//   or are handed to the next row, so scores are (double, integer scale) pairs: the running maximum
+//   is kept normalised (mantissa in [0.5,1), scale G), an incoming score is shifted onto that scale
+//   before the comparison, and G travels with the score — which is all the tie tolerance of
+//   xm::gt_tol needs.
 //
-// Spill: 8 B per cell (+4 B per step for L) instead of 12 B per cell.
+// Memory: spill 8 B per cell (+4 B of scale per RS steps) instead of 12 B per cell; no row table in
+// LDS (lane3_kernel prepares per-sweep lane records, a lane fetches its next row one row ahead into
+// registers), so 9.4 KB of LDS and 120 VGPRs give 16 waves per CU.  Launch: reads are handed to the
+// persistent waves longest first (launch_order); reads whose skew exceeds ALIGN1_C_CAP run in a
+// second launch with larger rings and a longer rescale period.
 #include <math.h>
 
 #include "nvk_internal.h"
