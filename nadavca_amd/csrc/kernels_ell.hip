@@ -22,7 +22,7 @@
 // positions plus one closing lane that applies the last wobble row and accumulates
 // sum_x cur[x] * suffix[last+1][x].
 //
-// Phase C has two implementations of the same recurrences.  Wrong-base hypotheses routinely couple
+// The kernel has two variants of the same recurrences (template parameter FAST).  Wrong-base hypotheses routinely couple
 // quantities that are thousands of bits apart (a k-mer 40 sigma off costs ~1000 bits per sample), so
 // every value keeps its own exponent in both; plain doubles under a shared scale were tried and lose
 // exactly the terms that decide such hypotheses.  The default (FAST) variant makes the scaled numbers
@@ -32,7 +32,12 @@
 //   * ONE table-based density per lane (dens.h) delivered directly as (mantissa, exponent); the
 //     mixture's other component and the predecessor value come from the neighbouring lane with DPP row
 //     shifts (lane rho at step u works on the cell lane rho-1 worked on at step u-1) — no LDS traffic;
-//   * the three input streams are prefetched in place (no double-buffer copies).
+//   * the three input streams are prefetched in place (no double-buffer copies); cells outside a
+//     stream's band are redirected to a zero cell of the row store instead of being masked;
+//   * the sweeps use the same arithmetic: a lane's mixture partner is its left neighbour's own density
+//     at the same cell, handed over through the LDS ring with the emitting value, which is normalised
+//     at EVERY hand-over (a dominating value passes its mantissa on; a systematic factor per hand-over
+//     would compound to 2^-R or 2^+R along the lanes).
 // The exact variant (NADAVCA_ELL_KERNEL=1, and k-mers longer than 6) is the original formulation with
 // two polynomial densities per lane and LDS hand-over; both agree to ~1e-15 relative
 // (tools/dbg_ell.py, tests/test_gpu_ell.py).
