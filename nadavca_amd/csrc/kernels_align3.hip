@@ -80,14 +80,19 @@ struct __attribute__((aligned(16))) Lane3 {
   int32_t end;       // forward: band end `be`; reverse: span end `hi` (with i + mel <= N folded in)
   int32_t lo;        // forward: span start (with i - mel >= 0 folded in); reverse: unused
   int32_t pbs, pbe;  // band of the row the lane receives from (empty for the sweep's first row)
-  int32_t mel;       // min event length of the applied step
+  int32_t mg;        // min event length of the applied step | gap << 4 | adv << 12, where gap is the
+                     // time offset between this row and the row it receives from (the neighbour's value
+                     // is gap + mel steps old) and adv the offset between this row and the lane's
+                     // previous row of the sweep (64 rows back) — RowParam::off, kernels_plan.hip
 };
+__device__ __forceinline__ int lane3_pack(int mel, int gap, int adv) { return mel | (gap << 4) | (adv << 12); }
 static_assert(sizeof(Lane3) == 48, "Lane3 layout");
 
 struct Align3Args {
   const ReadMeta *metas;
   const Lane3 *fwdl;
   const Lane3 *revl;
+  const int32_t *offs;  // per-row time offsets, [row]
   const double *signal;
   double *spill_v;   // suffix values, [slot][step][lane], scaled by 2^L(step)
   int32_t *spill_L;  // [slot][reverse step / RS] running log-scale of the reverse sweep
@@ -112,12 +117,12 @@ struct Align3Args {
 __device__ __forceinline__ void set_density_consts(Lane3 &l, const RowParam &o) {
   l.mean = o.mean;
   dens::scale_consts(o.ac, o.mc, l.ac, l.mc);
-  l.mel = o.mel;
 }
 
 // one block per read: RowParam rows -> per-sweep lane records
 __global__ __launch_bounds__(256) void lane3_kernel(const ReadMeta *metas, const RowParam *rows,
-                                                    Lane3 *fwdl, Lane3 *revl, int n_reads) {
+                                                    Lane3 *fwdl, Lane3 *revl, int32_t *offs,
+                                                    int n_reads) {
   const int rd = blockIdx.x;
   if (rd >= n_reads) return;
   const ReadMeta m = metas[rd];
@@ -129,13 +134,16 @@ __global__ __launch_bounds__(256) void lane3_kernel(const ReadMeta *metas, const
     Lane3 f, b;
     // forward: applies step r-1 -> r
     f.bs = o.bs; f.end = o.be; f.lo = o.lo;
+    const int adv_f = (r >= 64) ? o.off - rw[r - 64].off : 0;
+    const int adv_b = (r + 64 <= top) ? rw[r + 64].off - o.off : 0;
     if (r > 0) {
       const RowParam p = rw[r - 1];
       set_density_consts(f, p);
       f.pbs = p.bs; f.pbe = p.be;
       f.lo = max(o.lo, p.mel);
+      f.mg = lane3_pack(p.mel, o.off - p.off, adv_f);
     } else {
-      f.mean = 0.0; f.ac = 0.0; f.mc = 0.0; f.mel = 0; f.pbs = 0; f.pbe = -1;
+      f.mean = 0.0; f.ac = 0.0; f.mc = 0.0; f.mg = lane3_pack(0, 1, 0); f.pbs = 0; f.pbe = -1;
     }
     // reverse: applies step r -> r+1
     set_density_consts(b, o);
@@ -144,18 +152,22 @@ __global__ __launch_bounds__(256) void lane3_kernel(const ReadMeta *metas, const
       const RowParam q = rw[r + 1];
       b.pbs = q.bs; b.pbe = q.be;
       b.end = min(o.hi, N - o.mel);
+      b.mg = lane3_pack(o.mel, q.off - o.off, adv_b);
     } else {
       b.pbs = 0; b.pbe = -1;
       b.end = o.hi;
+      b.mg = lane3_pack(o.mel, 1, adv_b);
     }
     fwdl[m.row_off + r] = f;
     revl[m.row_off + r] = b;
+    offs[m.row_off + r] = o.off;
   }
 }
 
 #define TAKE_LANE(l)                                                                   \
   do {                                                                                 \
-    mean = (l).mean; ac2 = (l).ac; mc2 = (l).mc; melr = (l).mel;                       \
+    mean = (l).mean; ac2 = (l).ac; mc2 = (l).mc; melr = (l).mg & 15;                   \
+    D = (((l).mg >> 4) & 255) + melr;                                                  \
     bs = (l).bs; pbs = (l).pbs; pbe = (l).pbe;                                         \
   } while (0)
 
@@ -226,15 +238,15 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
     const int N = __builtin_amdgcn_readfirstlane(m.N);
     const int c = __builtin_amdgcn_readfirstlane(m.c);
     const int t_min = __builtin_amdgcn_readfirstlane(m.t_min);
-    const int n_steps = __builtin_amdgcn_readfirstlane(m.n_steps);
+    const int n_steps = __builtin_amdgcn_readfirstlane(m.pad);  // steps under the per-row offsets
     const int t_max = t_min + n_steps - 1;
     const Lane3 *fwdl = g.fwdl + m.row_off;
     const Lane3 *revl = g.revl + m.row_off;
+    const int32_t *offs = g.offs + m.row_off;  // cell (r, i) is computed at step t = i + offs[r]
     const double *sig = g.signal + m.sig_off;
     const int top = T - 1;
     int K = 0;          // true exponent of the largest suffix[0][.]
     bool suspect = false;  // something left the double range: the exact kernel must redo this read
-    const int sA0 = ((-c - MEL) % H + H) % H, sB0 = ((-c) % H + H) % H;
     const int RSH = RSHC ? RSHC : g.rsh, RS = 1 << RSH;
 
     // =========================== reverse sweep: suffix rows -> spill ===========================
@@ -243,23 +255,25 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
       // Lanes without a row keep bs = hi = -big: never active, never finished.  For the other
       // rows `hi` already folds the "predecessor column exists" test (i + mel <= N).
       double mean = 0, ac2 = 0, mc2 = 0;
-      int bs = -0x40000000, hi = -0x40000000, pbs = 0, pbe = -1, melr = 0;
+      int bs = -0x40000000, hi = -0x40000000, pbs = 0, pbe = -1, melr = 0, D = 1;
       bool is_init = false;
       Lane3 nx;  // the lane's next row (r - 64), fetched one row ahead
-      nx.mean = nx.ac = nx.mc = 0.0; nx.bs = nx.end = nx.lo = nx.pbs = nx.pbe = nx.mel = 0;
+      nx.mean = nx.ac = nx.mc = 0.0; nx.bs = nx.end = nx.lo = nx.pbs = nx.pbe = nx.mg = 0;
+      int i = t_max;
       if (r >= 0) {
         const Lane3 cu = revl[r];
         TAKE_LANE(cu);
         hi = cu.end;
         is_init = (r == top);
         if (r >= 64) nx = revl[r - 64];
+        i = t_max - offs[r];
       }
-      int i = t_max - c * r;
       double prev = 0.0, e1 = 1.0, e2 = 1.0, e3 = 1.0;
       int kmax = -0x40000000;
       int r_old = top;
-      int filled_lo = ((t_max - c * top) / CH + 1) * CH;
-      while (t_max - c * r_old < filled_lo) {
+      int i_old = __builtin_amdgcn_readlane(i, top & 63);  // sample index of the oldest open row (scalar)
+      int filled_lo = (i_old / CH + 1) * CH;
+      while (i_old < filled_lo) {
         filled_lo -= CH;
         for (int q = lane; q < CH; q += 64) {
           int idx = filled_lo + q;
@@ -269,7 +283,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
       __syncthreads();
       Scale sc{0, 0, 0};
       double e = density(ring[i & RM], mean, ac2, mc2, 0, etab);
-      int su = 0, sA = sA0, sB = sB0;
+      int su = 0;
       bool init_live = true;  // (uniform) the last row is still being swept
 
       for (int u = 0; u < n_steps; ++u) {
@@ -285,7 +299,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
         if (__any(fin)) {
           if (fin) {
             r -= 64;
-            i += 64 * c;
+            i += nx.mg >> 12;
             prev = 0.0;
             if (r >= 0) {
               TAKE_LANE(nx);
@@ -301,10 +315,11 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
           // expose its full latency at every switch.
           nx = revl[max(r - 64, 0)];
           while (r_old >= 0 && __builtin_amdgcn_readlane(r, r_old & 63) != r_old) r_old--;
+          i_old = __builtin_amdgcn_readlane(i, r_old & 63);
           init_live = init_live && (__builtin_amdgcn_readlane(r, top & 63) == top);
         }
         if (r_old >= 0) {
-          int need_min = t - 1 - c * r_old;
+          const int need_min = i_old - 1;
           while (need_min < filled_lo) {
             filled_lo -= CH;
             __syncthreads();
@@ -316,7 +331,8 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
           }
         }
         // LDS reads first: the neighbour's value and the sample of the next step's density
-        const int hs = (melr == 0 ? sB : sA) * 64 + ((lane + 1) & 63);
+        // the neighbour's value is D = gap + mel steps old: slot (su - D) mod H
+        const int hs = (int)min((unsigned)(su - D), (unsigned)(su - D + H)) * 64 + ((lane + 1) & 63);
         const double xn = ring[(i - 1) & RM];
         double pv = hist[hs];
         // scalar shifts that bring a neighbour value from D steps ago to the current scale
@@ -330,10 +346,9 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
         const int j = i + melr;
         pv = (j >= pbs && j <= pbe) ? pv : 0.0;
         double t1 = P * pv;
-        if (sh_any) {  // D = c for mel 0 rows; D = c + MEL otherwise, beyond the densities' own shifts
-          const int shT = (age < c) ? sc.d_last : 0, shE = (age >= MEL) ? sc.d_last : 0;
+        if (sh_any) {  // the value is D steps old; the last mel of those shifts are in the densities of P
           asm volatile("");
-          t1 = ldexp(t1, melr == 0 ? shT : shE);
+          t1 = ldexp(t1, (age >= melr && age < D) ? sc.d_last : 0);
         }
         double o = fma(e, prev, t1);
         o = active ? o : 0.0;
@@ -363,11 +378,10 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
           suspect |= (mx > -0x40000000) && (TARGET - mx > DMAX);
         }
         i -= 1;
+        i_old -= 1;
         e3 = e2; e2 = e1; e1 = e;
         e = density_end(dn, sc.d_next);
         su = (su + 1 == H) ? 0 : su + 1;
-        sA = (sA + 1 == H) ? 0 : sA + 1;
-        sB = (sB + 1 == H) ? 0 : sB + 1;
         WAVE_SYNC();
       }
       K = __builtin_amdgcn_readfirstlane(kmax);
@@ -384,18 +398,19 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
       // Lanes without a row keep lo = be = +big: never active, never finished.  For the other rows
       // `lo` already folds the "predecessor column exists" test (i - mel >= 0).
       double mean = 0, ac2 = 0, mc2 = 0;
-      int bs = 0, be = 0x40000000, lo = 0x40000000, pbs = 0, pbe = -1, melr = 0;
+      int bs = 0, be = 0x40000000, lo = 0x40000000, pbs = 0, pbe = -1, melr = 0, D = 1;
       bool is_init = false;
       Lane3 nx;  // the lane's next row (r + 64), fetched one row ahead
-      nx.mean = nx.ac = nx.mc = 0.0; nx.bs = nx.end = nx.lo = nx.pbs = nx.pbe = nx.mel = 0;
+      nx.mean = nx.ac = nx.mc = 0.0; nx.bs = nx.end = nx.lo = nx.pbs = nx.pbe = nx.mg = 0;
+      int i = t_min - 64 * c;
       if (r < T) {
         const Lane3 cu = fwdl[r];
         TAKE_LANE(cu);
         be = cu.end; lo = cu.lo;
         is_init = (r == 0);
         if (r + 64 < T) nx = fwdl[r + 64];
+        i = t_min - offs[r];
       }
-      int i = t_min - c * r;
       double prev = 0.0, e1 = 1.0, e2 = 1.0, e3 = 1.0;
       // path DP state of the row: running maximum of the previous row's scores (raw, as received,
       // and normalised by 2^rho), its tolerance margin, the row's accumulated exponent G
@@ -408,6 +423,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
       double rsum = 0.0, smin = INFINITY, smax = 0.0;
       uint32_t bits = 0;
       int r_old = 0;
+      int i_old = t_min;  // sample index of the oldest open row (scalar): offs[0] = 0
       int filled_hi = ((t_min - MEL - 1) > 0 ? (t_min - MEL - 1) / CH : 0) * CH;
       while (t_min - 1 >= filled_hi) {
         for (int w = lane; w < CH; w += 64) {
@@ -419,7 +435,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
       __syncthreads();
       Scale sc{0, 0, 0};
       double e = density(ring[(i - 1) & RM], mean, ac2, mc2, 0, etab);
-      int su = 0, sA = sA0, sB = sB0;
+      int su = 0;
       bool init_live = true;  // (uniform) row 0 is still being swept
       bool top_live = (top < 64); // (uniform) the last row has been started
 
@@ -438,7 +454,6 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
         for (int q = 0; q < PF; q++) {
           const int u = ub + q;
           if (u < n_steps) {
-            const int t = t_min + u;
             const int age = u & (RS - 1);
             if (age == 0 && u > 0) {
               sc.L += sc.d_next;
@@ -452,7 +467,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
                 smax = fmax(smax, rsum);
                 rsum = 0.0;
                 r += 64;
-                i -= 64 * c;
+                i -= nx.mg >> 12;
                 prev = 0.0;
                 bestn = 0.0; bthr = 0.0; G = GBIG;
                 if (r < T) {
@@ -466,11 +481,12 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
               }
               nx = fwdl[min(r + 64, top)];  // all lanes, see the reverse sweep
               while (r_old < T && __builtin_amdgcn_readlane(r, r_old & 63) != r_old) r_old++;
+              i_old = __builtin_amdgcn_readlane(i, r_old & 63);
               init_live = init_live && (__builtin_amdgcn_readfirstlane(r) == 0);
               top_live = (__builtin_amdgcn_readlane(r, top & 63) == top);
             }
             if (r_old < T) {
-              int need_max = t + 1 - c * r_old - 1;
+              const int need_max = i_old;
               while (need_max >= filled_hi) {
                 __syncthreads();
                 for (int w = lane; w < CH; w += 64) {
@@ -482,7 +498,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
               }
             }
             // LDS reads first: the neighbour's values and the sample of the next step's density
-            const int hs = (melr == 0 ? sB : sA) * 64 + ((lane - 1) & 63);
+            const int hs = (int)min((unsigned)(su - D), (unsigned)(su - D + H)) * 64 + ((lane - 1) & 63);
             const double xn = ring[i & RM];
             const double2 hv = hist2[hs];
             const int Gin = ghist[hs];
@@ -499,10 +515,9 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
             pv = ok ? pv : 0.0;
             dv = ok ? dv : 0.0;
             double t1 = P * pv;
-            if (sh_any) {  // D = c for mel 0 rows; D = c + MEL otherwise, beyond the densities' own shifts
-          const int shT = (age < c) ? sc.d_last : 0, shE = (age >= MEL) ? sc.d_last : 0;
+            if (sh_any) {  // see the reverse sweep
               asm volatile("");
-              t1 = ldexp(t1, melr == 0 ? shT : shE);
+              t1 = ldexp(t1, (age >= melr && age < D) ? sc.d_last : 0);
             }
             double o = fma(e, prev, t1);
             o = active ? o : 0.0;
@@ -564,11 +579,10 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
           suspect |= (mx > -0x40000000) && (TARGET - mx > DMAX);
             }
             i += 1;
+            i_old += 1;
             e3 = e2; e2 = e1; e1 = e;
             e = density_end(dn, sc.d_next);
             su = (su + 1 == H) ? 0 : su + 1;
-            sA = (sA + 1 == H) ? 0 : sA + 1;
-            sB = (sB + 1 == H) ? 0 : sB + 1;
             WAVE_SYNC();
           }
         }
@@ -603,7 +617,10 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
     if (lane == 0) {
       int32_t *ev = g.out_events + 2 * m.ref_off;
       int st = NVK_READ_OK;
+      int off_r = offs[top];
       for (int r = top; r >= 0; --r) {
+        const int off_c = off_r;
+        if (r > 0) off_r = offs[r - 1];  // next iteration's offset, fetched beside this one's bit words
         if (g.transitions) {
           ev[2 * (r >> 1) + (r & 1)] = idx;
         } else {
@@ -612,7 +629,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
         }
         if (r == 0) break;
         const int pm = g.transitions ? ((r - 1) & 1 ? 0 : MEL) : MEL;
-        int u = idx + c * r - t_min;
+        int u = idx + off_c - t_min;
         int w = u >> 5;
         uint32_t v = bp[(size_t)w * 64 + (r & 63)] & (0xffffffffu << (31 - (u & 31)));
         while (v == 0 && w > 0) {
@@ -625,7 +642,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
           break;
         }
         int uu = (w << 5) + (31 - (__ffs(v) - 1));
-        idx = uu + t_min - c * r - pm;
+        idx = uu + t_min - off_c - pm;
       }
       g.out_status[rd] = st;
     }
@@ -637,7 +654,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
 int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadMeta *metas,
                   const RowParam *rows, const PlanTotals &tot, int32_t *out_events,
                   int32_t *out_status, int *n_retry) {
-  static_assert(WS_LANE_F < (int)(sizeof(ctx->ws) / sizeof(ctx->ws[0])), "workspace table too small");
+  static_assert(WS_OFFS < (int)(sizeof(ctx->ws) / sizeof(ctx->ws[0])), "workspace table too small");
   *n_retry = 0;
   if (a.n_reads == 0) return NVK_OK;
   const int mel = a.mel;
@@ -653,6 +670,8 @@ int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadM
   rc = nvk_ws_reserve(ctx, WS_LANE_F, (size_t)(rows_total + 1) * sizeof(Lane3));
   if (rc) return rc;
   rc = nvk_ws_reserve(ctx, WS_LANE_R, (size_t)(rows_total + 1) * sizeof(Lane3));
+  if (rc) return rc;
+  rc = nvk_ws_reserve(ctx, WS_OFFS, (size_t)(rows_total + 1) * sizeof(int32_t));
   if (rc) return rc;
   int *counter = (int *)ctx->ws[WS_MISC];
   int *d_retry = counter + 2;
@@ -670,7 +689,8 @@ int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadM
   {
     TimerScope ts(ctx, NVK_K_PLAN);
     hipLaunchKernelGGL(lane3_kernel, dim3((unsigned)a.n_reads), dim3(256), 0, ctx->stream, metas, rows,
-                       (Lane3 *)ctx->ws[WS_LANE_F], (Lane3 *)ctx->ws[WS_LANE_R], (int)a.n_reads);
+                       (Lane3 *)ctx->ws[WS_LANE_F], (Lane3 *)ctx->ws[WS_LANE_R], (int32_t *)ctx->ws[WS_OFFS],
+                       (int)a.n_reads);
   }
   NVK_HIP(hipGetLastError());
   int *order = nullptr;
@@ -725,6 +745,7 @@ int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadM
     g.metas = metas;
     g.fwdl = (const Lane3 *)ctx->ws[WS_LANE_F];
     g.revl = (const Lane3 *)ctx->ws[WS_LANE_R];
+    g.offs = (const int32_t *)ctx->ws[WS_OFFS];
     g.signal = a.signal;
     g.spill_v = (double *)ctx->ws[WS_SPILL];
     g.spill_L = (int32_t *)ctx->ws[WS_STAGE];

@@ -199,7 +199,7 @@ __global__ __launch_bounds__(PLAN_T) void plan_kernel(DeviceModel dm, BatchArgs 
     p.ac = 0.0;
     p.mc = 0.0;
     p.mel = 0;
-    p.pad = 0;
+    p.off = 0;
     if (r + 1 < T) {
       if (mode == PLAN_ALIGN_TRANS && (r & 1)) {
         // transition step between base r/2 and r/2+1: constant log(0.01), -inf on equal means
@@ -252,12 +252,88 @@ __global__ __launch_bounds__(PLAN_T) void plan_kernel(DeviceModel dm, BatchArgs 
   const int c = sh_c;
   cells = (long long)sh_cells;
 
+  // --- per-row time offsets (variable skew, used by kernels_align3.hip) ---------------------------
+  // The uniform mapping t = i + c*r pays the worst pair of rows (r - 64, r) of the read on every row.
+  // Here cell (r, i) is computed at step t = i + off[r] with the LEAST offsets that satisfy
+  //   gmin <= off[r] - off[r-1] <= c            (neighbour values wait at most c + mel steps in LDS)
+  //   off[r] - off[r-64] >= hi[r-64] - lo[r] + 1  (a lane is free before its next row starts)
+  // (off[r] = c*r is one solution, so the least one exists and needs no more steps).  With
+  // x[r] = off[r] - gmin*r the first lower bound and the second are a prefix maximum per block of 64
+  // rows, and the upper bound is a suffix maximum of x[r] - (c-gmin)*r; both are iterated to the
+  // fixed point by wave 0 (2-3 rounds on config-shaped reads).  Reads with more rows than the LDS
+  // arrays hold keep the uniform offsets.
+  constexpr int VT = 2048;
+  __shared__ int sh_k[VT], sh_x[VT];
+  __shared__ int sh_var;
+  const int gmin = max(mel - 1, 1);
+  const int G1 = c - gmin;
+  if (tid == 0) sh_var = 0;
+  __syncthreads();
+  if (T <= VT && T > 64 && G1 > 0) {
+    for (int r = tid; r < T; r += PLAN_T) {
+      sh_k[r] = (r >= 64) ? rp[r - 64].hi - rp[r].lo + 1 - 64 * gmin : 0;
+      sh_x[r] = 0;
+    }
+    __syncthreads();
+    if (tid < 64) {
+      const int NEG = -0x20000000;
+      bool changed = true;
+      int iter = 0;
+      while (changed && iter < 64) {
+        changed = false;
+        ++iter;
+        int carry = 0;
+        for (int b0 = 0; b0 < T; b0 += 64) {  // lower bounds, ascending
+          const int r = b0 + lane;
+          const int cur = r < T ? sh_x[r] : NEG;
+          int v = cur;
+          if (r < T && r >= 64) v = max(v, sh_x[r - 64] + sh_k[r]);
+          for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(v, d, 64);
+            if (lane >= d) v = max(v, o);
+          }
+          v = max(v, carry);
+          if (r < T) {
+            changed |= (v != cur);
+            sh_x[r] = v;
+          }
+          carry = __shfl(v, 63, 64);
+        }
+        int carryz = NEG;
+        for (int b0 = ((T - 1) / 64) * 64; b0 >= 0; b0 -= 64) {  // gap limit, descending
+          const int r = b0 + lane;
+          const int cur = r < T ? sh_x[r] : 0;
+          int z = r < T ? cur - G1 * r : NEG;
+          for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_down(z, d, 64);
+            if (lane + d < 64) z = max(z, o);
+          }
+          z = max(z, carryz);
+          if (r < T) {
+            const int nx = z + G1 * r;
+            changed |= (nx != cur);
+            sh_x[r] = nx;
+          }
+          carryz = __shfl(z, 0, 64);
+        }
+        changed = __any(changed);
+      }
+      if (lane == 0) sh_var = changed ? 0 : 1;  // not converged (never seen): uniform offsets
+    }
+    __syncthreads();
+  }
+  const bool var_ok = (sh_var != 0);
+  const int x0 = var_ok ? sh_x[0] : 0;
+  for (int r = tid; r < T; r += PLAN_T) rp[r].off = var_ok ? sh_x[r] - x0 + gmin * r : c * r;
+  const int off_top = var_ok ? sh_x[T - 1] - x0 + gmin * (T - 1) : c * (T - 1);
+
   if (tid == 0) {
     int t_min = rp[0].lo;
     int t_max = rp[T - 1].hi + c * (T - 1);
     m.c = c;
     m.t_min = t_min;
     m.n_steps = t_max - t_min + 1;
+    m.pad = rp[T - 1].hi + off_top - t_min + 1;  // steps under the per-row offsets
     m.cells = cells;
     if (badband) m.status = NVK_READ_BAD_BAND;
     metas[rd] = m;
@@ -267,7 +343,7 @@ __global__ __launch_bounds__(PLAN_T) void plan_kernel(DeviceModel dm, BatchArgs 
       if (c > c_cap) atomicAdd(&totals->n_wide, 1);
       atomicMax(&totals->max_T, T);
       atomicAdd(&totals->cells, (unsigned long long)cells);
-      atomicAdd(&totals->steps, (unsigned long long)m.n_steps);
+      atomicAdd(&totals->steps, (unsigned long long)m.pad);
     }
   }
 }

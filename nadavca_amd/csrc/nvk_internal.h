@@ -16,7 +16,7 @@ struct __attribute__((aligned(16))) RowParam {
   int32_t bs, be;          // band of row r, inclusive sample-boundary indices
   int32_t lo, hi;          // lane occupancy of row r: band + warm-up/pre-roll on both sides
   int32_t mel;             // min event length of step r -> r+1
-  int32_t pad;
+  int32_t off;             // per-row time offset: kernels_align3 computes cell (r, i) at step i + off[r]
 };
 static_assert(sizeof(RowParam) == 48, "RowParam layout");
 
@@ -63,7 +63,8 @@ struct ReadMeta {
   int32_t t_min;     // first step
   int32_t n_steps;   // number of steps
   int32_t status;    // NVK_READ_*
-  int32_t pad;
+  int32_t pad;       // align planner: number of steps under the per-row offsets RowParam::off;
+                     // paired planner: first step of the mirrored sweep
   int64_t cells;     // sum of band widths (algorithmic cell count)
 };
 
@@ -86,7 +87,7 @@ struct DeviceModel {
 
 // ----- host-side objects ------------------------------------------------------------------
 enum { WS_META = 0, WS_ROWS = 1, WS_BANDTMP = 2, WS_SPILL = 3, WS_BP = 4, WS_MISC = 5, WS_ROWS2 = 6, WS_STAGE = 7,
-       WS_SPILL_B = 8, WS_STAGE_B = 9, WS_BP_B = 10, WS_LANE_F = 11, WS_LANE_R = 12, WS_ORDER = 13, WS_COUNT = 14 };
+       WS_SPILL_B = 8, WS_STAGE_B = 9, WS_BP_B = 10, WS_LANE_F = 11, WS_LANE_R = 12, WS_ORDER = 13, WS_OFFS = 14, WS_COUNT = 15 };
 
 struct nvk_ctx {
   int device;
