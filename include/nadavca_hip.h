@@ -67,7 +67,8 @@ enum {
   NVK_K_EXPECTED = 4,    /* expected-level gather */
   NVK_K_CONSENSUS = 5,   /* normalise + strand flip + scatter-add */
   NVK_K_POSTERIOR = 6,   /* windowed posterior */
-  NVK_K_COUNT = 7
+  NVK_K_RENORM = 7,      /* normalisation, per-event means, linear re-fit (align_signal's renorm loop) */
+  NVK_K_COUNT = 8
 };
 
 const char *nvk_last_error(void); /* thread-local message of the last failing call */
@@ -193,6 +194,36 @@ int nvk_posterior_segments_dev(nvk_ctx *ctx, int64_t len, int64_t n_segments, co
 /* host-pointer flavour; seg_off may be NULL for a single group */
 int nvk_posterior(nvk_ctx *ctx, int64_t len, int64_t n_segments, const int64_t *seg_off, int alphabet,
                   int k, double snp_prior, const double *ll, const int32_t *reference, double *out);
+
+/* ---- host steps adjacent to the path, on the device ------------------------ */
+
+/* replaces Read.normalize_reads (/root/reference/nadavca/read.py:68-81) for n_groups independent
+ * groups of samples laid end to end (group g = raw[grp_off[g] .. grp_off[g+1])):
+ *   centre = median, scale = median |x - centre| (exact selections, the mean of the two middle
+ *   values for an even count), out = clip((x - centre) / scale, -5, 5).
+ * align_signal normalises every read on its own (one group per read, align_signal.py:54),
+ * estimate_snps all reads together (one group, estimate_snps.py:61).  out may alias raw;
+ * centre_scale f64[2*n_groups] receives (centre, scale) per group, or NULL.  Device pointers. */
+int nvk_normalize_groups_dev(nvk_ctx *ctx, int64_t n_groups, const double *raw, const int64_t *grp_off,
+                             double *out, double *centre_scale);
+
+/* replaces the per-event numpy.mean of align_signal.py:66-69 and read.py:85-86: for every base g of
+ * every read, the mean of signal[sig_off[read] + events[2g] .. + events[2g+1]) with `events` as written
+ * by nvk_refine_alignment_batch_dev (slice coordinates).  Summation in numpy's pairwise order, so the
+ * result equals numpy.mean bit for bit; an empty event or a read with status != 0 gives NaN.
+ * out_means f64[total_ref].  Device pointers; status may be NULL. */
+int nvk_event_means_dev(nvk_ctx *ctx, int64_t n_reads, int64_t total_ref, const double *signal,
+                        const int64_t *sig_off, const int32_t *events, const int64_t *ref_off,
+                        const int32_t *status, double *out_means);
+
+/* replaces scipy.stats.linregress(expected, means) and the rescale that follows it
+ * (align_signal.py:71-73), per read:  slope = cov(x, y) / var(x), intercept = mean(y) - slope * mean(x),
+ * then signal[sig_off[read] ..] = (signal - intercept) / slope in place.  Reads with status != 0 are
+ * left alone.  out_fit f64[2*n_reads] receives (slope, intercept) so that the caller can apply the same
+ * map to samples outside the slice, or NULL.  Device pointers. */
+int nvk_linfit_rescale_dev(nvk_ctx *ctx, int64_t n_reads, const double *expected, const double *means,
+                           const int64_t *ref_off, const int32_t *status, double *signal,
+                           const int64_t *sig_off, double *out_fit);
 
 #ifdef __cplusplus
 }

@@ -22,8 +22,8 @@ READ_NO_PATH = 1
 READ_BAD_INPUT = -1
 READ_BAD_BAND = -2
 
-K_PLAN, K_ALIGN, K_ELL_SWEEP, K_ELL_HYP, K_EXPECTED, K_CONSENSUS, K_POSTERIOR = range(7)
-KERNEL_NAMES = ['plan', 'align', 'ell_sweep', 'ell_hyp', 'expected', 'consensus', 'posterior']
+K_PLAN, K_ALIGN, K_ELL_SWEEP, K_ELL_HYP, K_EXPECTED, K_CONSENSUS, K_POSTERIOR, K_RENORM = range(8)
+KERNEL_NAMES = ['plan', 'align', 'ell_sweep', 'ell_hyp', 'expected', 'consensus', 'posterior', 'renorm']
 
 _vp = C.c_void_p
 _i64 = C.c_int64
@@ -58,6 +58,9 @@ SIGNATURES = {
     'nvk_consensus_accumulate': (_int, [_vp, _i64, _int] + [_vp] * 6 + [_dbl, _i64, _vp, _vp]),
     'nvk_posterior_segments_dev': (_int, [_vp, _i64, _i64, _vp, _int, _int, _dbl, _vp, _vp, _vp]),
     'nvk_posterior': (_int, [_vp, _i64, _i64, _vp, _int, _int, _dbl, _vp, _vp, _vp]),
+    'nvk_normalize_groups_dev': (_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
+    'nvk_event_means_dev': (_int, [_vp, _i64, _i64] + [_vp] * 6),
+    'nvk_linfit_rescale_dev': (_int, [_vp, _i64] + [_vp] * 7),
 }
 
 _lib = None

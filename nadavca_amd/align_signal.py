@@ -3,14 +3,13 @@
 Generator of ``(read, (approximate_alignment, alignment))`` with ``alignment`` the (R, 3) int
 array (reference position, event start, event end).  The per-read renormalise / re-align loop of
 the reference (renorm_rounds, default 3: linear re-fit, re-align, linear re-fit) is kept, but every
-round processes all reads in one batched GPU launch.  Extensions over the reference signature,
-both optional: ``reads`` may hold ``Read`` objects (not only fast5 paths), and ``aligner`` injects
-an approximate aligner (BWA is not available offline)."""
+round processes all reads in one batched GPU launch, and the signal stays on the device between the
+rounds (per-event means, least-squares re-fit and rescale are kernels: include/nadavca_hip.h).
+Extensions over the reference signature, both optional: ``reads`` may hold ``Read`` objects (not only
+fast5 paths), and ``aligner`` injects an approximate aligner (BWA is not available offline)."""
 import sys
 
-import numpy as np
 import yaml
-from scipy.stats import linregress
 
 from . import defaults
 from .alignment import ApproximateAligner
@@ -49,17 +48,6 @@ def load_model_and_estimator(reference_filename, config=defaults.CONFIG_FILE, km
     return kmer_model, ProbabilityEstimator(kmer_model, aligner, config)
 
 
-def _renormalize(kmer_model, read, apx_alignment, alignment):
-    """One linear re-fit of the read's normalisation against the model (align_signal.py:59-76)."""
-    bases = [{'A': 0, 'C': 1, 'G': 2, 'T': 3}[x] for x in apx_alignment.reference_part]
-    expected = np.array(kmer_model.get_expected_signal(bases, [], []))
-    al_start = alignment[0][1]
-    signal_cut = read.normalized_signal[alignment[0][1]:alignment[-1][2]]
-    means = [np.mean(signal_cut[s - al_start:e - al_start]) for _, s, e in alignment]
-    slope, intercept, _, _, _ = linregress(expected, means)
-    read.normalized_signal = (read.normalized_signal - intercept) / slope
-
-
 def align_signal(reference_filename, reads, config=defaults.CONFIG_FILE,
                  kmer_model=defaults.KMER_MODEL_FILE, bwa_executable=defaults.BWA_EXECUTABLE,
                  group_name=defaults.GROUP_NAME, renorm_rounds=defaults.RENORM_ROUNDS, aligner=None):
@@ -67,21 +55,12 @@ def align_signal(reference_filename, reads, config=defaults.CONFIG_FILE,
     if loaded is None:
         return
     kmer_model, estimator = loaded
-    loaded_reads = []
-    for item in reads:
-        read = Read.load_from_fast5(item, group_name) if isinstance(item, str) else item
-        Read.normalize_reads([read])  # per-read normalisation (align_signal.py:54)
-        loaded_reads.append(read)
-    results = estimator.get_refined_alignments(loaded_reads)
-    for r in range(renorm_rounds):
-        live = [i for i, res in enumerate(results) if res is not None]
-        if r % 2 == 0:
-            for i in live:
-                _renormalize(kmer_model, loaded_reads[i], *results[i])
-        else:
-            again = estimator.get_refined_alignments([loaded_reads[i] for i in live])
-            for i, res in zip(live, again):
-                results[i] = res
+    loaded_reads = [Read.load_from_fast5(item, group_name) if isinstance(item, str) else item
+                    for item in reads]
+    # per-read normalisation (align_signal.py:54), all reads in one kernel
+    Read.normalize_reads_device(loaded_reads, per_read=True, context=kmer_model.context)
+    # align / re-fit / re-align / re-fit (align_signal.py:55-80), device-resident
+    results = estimator.refine_and_renormalize(loaded_reads, renorm_rounds)
     for read, res in zip(loaded_reads, results):
         if res is None:
             # the reference raises TypeError here (it unpacks None, align_signal.py:55)

@@ -82,3 +82,88 @@ def estimate_log_likelihoods_dev(dbatch, bandwidth, min_event_length, kmer_model
         *dbatch.pointers(), int(bandwidth), int(min_event_length), int(bool(model_wobbling)),
         _dp(ll), _dp(status)), 'nvk_estimate_log_likelihoods_batch_dev')
     return ll, status
+
+
+# ---- host steps adjacent to the path, on the device (include/nadavca_hip.h) --------
+def normalize_groups_dev(context, raw, grp_off, out=None):
+    """``Read.normalize_reads`` for groups of samples laid end to end (torch f64 / int64 tensors on the
+    context's device): -> (normalised signal, (n_groups, 2) tensor of (centre, scale))."""
+    import torch
+    lib = _lib.load()
+    n_groups = int(grp_off.numel()) - 1
+    if out is None:
+        out = torch.empty_like(raw)
+    cs = torch.zeros((max(n_groups, 0), 2), dtype=torch.float64, device=raw.device)
+    _lib.check(lib.nvk_normalize_groups_dev(context.handle, n_groups, _dp(raw), _dp(grp_off), _dp(out),
+                                            _dp(cs)), 'nvk_normalize_groups_dev')
+    return out, cs
+
+
+def expected_levels_dev(dbatch, kmer_model, with_contexts=True):
+    """``KmerModel.get_expected_signal`` for every read of the batch -> f64 (sum R,).  Without contexts
+    the k-mers at the ends are padded with base 0, as ``get_expected_signal(bases, [], [])`` does
+    (align_signal.py:63)."""
+    torch = dbatch.torch
+    lib = _lib.load()
+    out = torch.zeros(dbatch.total_ref, dtype=torch.float64, device=dbatch.device)
+    if with_contexts:
+        cb, cbo, ca, cao = dbatch.context_before, dbatch.cb_off, dbatch.context_after, dbatch.ca_off
+    else:
+        cb = ca = torch.zeros(1, dtype=torch.int32, device=dbatch.device)
+        cbo = cao = torch.zeros(dbatch.n + 1, dtype=torch.int64, device=dbatch.device)
+    _lib.check(lib.nvk_expected_signal_batch_dev(
+        kmer_model.handle, dbatch.n, dbatch.total_ref, _dp(dbatch.reference), _dp(dbatch.ref_off),
+        _dp(cb), _dp(cbo), _dp(ca), _dp(cao), _dp(out)), 'nvk_expected_signal_batch_dev')
+    return out
+
+
+def event_means_dev(dbatch, context, events, status=None):
+    """Mean of the batch's signal over every event of ``events`` (as returned by
+    ``refine_alignment_dev``) -> f64 (sum R,); equals ``numpy.mean`` of the same samples bit for bit."""
+    torch = dbatch.torch
+    lib = _lib.load()
+    out = torch.zeros(dbatch.total_ref, dtype=torch.float64, device=dbatch.device)
+    _lib.check(lib.nvk_event_means_dev(
+        context.handle, dbatch.n, dbatch.total_ref, _dp(dbatch.signal), _dp(dbatch.sig_off), _dp(events),
+        _dp(dbatch.ref_off), _dp(status) if status is not None else C.c_void_p(0), _dp(out)),
+        'nvk_event_means_dev')
+    return out
+
+
+def linfit_rescale_dev(dbatch, context, expected, means, status=None):
+    """Per read: least-squares line of ``means`` on ``expected`` and ``signal = (signal - intercept) /
+    slope`` in place on the batch's signal -> (n, 2) tensor of (slope, intercept)."""
+    torch = dbatch.torch
+    lib = _lib.load()
+    fit = torch.zeros((dbatch.n, 2), dtype=torch.float64, device=dbatch.device)
+    _lib.check(lib.nvk_linfit_rescale_dev(
+        context.handle, dbatch.n, _dp(expected), _dp(means), _dp(dbatch.ref_off),
+        _dp(status) if status is not None else C.c_void_p(0), _dp(dbatch.signal), _dp(dbatch.sig_off),
+        _dp(fit)), 'nvk_linfit_rescale_dev')
+    return fit
+
+
+def refine_renorm_loop_dev(dbatch, bandwidth, min_event_length, kmer_model, model_transitions,
+                           renorm_rounds):
+    """The renormalise / re-align loop of ``align_signal`` (align_signal.py:55-80) for a whole batch
+    without leaving the device: align; then for round r = 0 .. renorm_rounds-1: even r — per-event
+    means, linear re-fit against the model's expected levels (empty contexts), rescale the signal;
+    odd r — align again.  -> (events, status, [fit tensors of the even rounds]).  ``dbatch.signal`` is
+    rescaled in place."""
+    context = kmer_model.context
+    events, status = refine_alignment_dev(dbatch, bandwidth, min_event_length, kmer_model, model_transitions)
+    expected, fits = None, []
+    for r in range(int(renorm_rounds)):
+        if r % 2 == 0:
+            if expected is None:
+                expected = expected_levels_dev(dbatch, kmer_model, with_contexts=False)
+            means = event_means_dev(dbatch, context, events, status)
+            fits.append(linfit_rescale_dev(dbatch, context, expected, means, status))
+        else:
+            # a read that lost its path stays lost (the reference raises on it at this point)
+            new_events, new_status = refine_alignment_dev(dbatch, bandwidth, min_event_length, kmer_model,
+                                                          model_transitions)
+            keep = status != 0
+            new_status[keep] = status[keep]
+            events, status = new_events, new_status
+    return events, status, fits

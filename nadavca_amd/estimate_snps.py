@@ -45,7 +45,8 @@ def estimate_snps(reference_filename, reads, reference=None, config=defaults.CON
         reads = [os.path.join(base, f) for f in os.listdir(base)
                  if f.endswith('.fast5') and not os.path.isdir(os.path.join(base, f))]
     reads = [Read.load_from_fast5(r, group_name) if isinstance(r, str) else r for r in reads]
-    Read.normalize_reads(reads)  # ONE median/MAD over all reads (estimate_snps.py:61)
+    # ONE median/MAD over all reads (estimate_snps.py:61)
+    Read.normalize_reads_device(reads, context=getattr(kmer_model, 'context', None))
 
     if independent:
         chunks = estimator.estimate_probabilities_independent(reference, reads)

@@ -128,6 +128,53 @@ class ProbabilityEstimator:
     def get_refined_alignment(self, read):
         return self.get_refined_alignments([read])[0]
 
+    def _alignment_rows(self, p, ev):
+        s0 = p.signal_range[0]
+        start_ref, end_ref = p.apx.reference_range
+        res = numpy.zeros((len(ev), 3), dtype=int)
+        pos = numpy.arange(len(ev))
+        res[:, 0] = (end_ref - pos - 1) if p.apx.reverse_complement else (start_ref + pos)
+        res[:, 1] = ev[:, 0] + s0
+        res[:, 2] = ev[:, 1] + s0
+        return res
+
+    def refine_and_renormalize(self, reads, renorm_rounds):
+        """``align_signal``'s per-read loop (align_signal.py:55-80) for all reads at once and without
+        leaving the device between rounds: align, then alternately re-fit the normalisation linearly
+        against the model's expected levels (even rounds) and align again (odd rounds) —
+        ``device.refine_renorm_loop_dev``.  Every read's ``normalized_signal`` ends up rescaled as in
+        the reference.  -> list of (approximate_alignment, (R,3) int array) or None per read."""
+        import torch
+        from .device import DeviceBatch, refine_renorm_loop_dev
+        prepared = [self._prepare(r) for r in reads]
+        live = [p for p in prepared if p is not None]
+        if not live:
+            return [None] * len(prepared)
+        batch = dtw.FlatBatch([self._dp_tuple(p, p.read.normalized_signal) for p in live])
+        dbatch = DeviceBatch(batch, torch.device('cuda', self.kmer_model.context.device))
+        events, status, fits = refine_renorm_loop_dev(dbatch, self.bandwidth, self.min_event_length,
+                                                      self.kmer_model, self.model_transitions, renorm_rounds)
+        events, status = events.cpu().numpy(), status.cpu().numpy()
+        fits = [f.cpu().numpy() for f in fits]
+        if (status < 0).any():
+            bad = numpy.nonzero(status < 0)[0]
+            raise ValueError('refine_alignment: invalid input for read(s) %s' % bad[:8].tolist())
+        out, j = [], 0
+        for p in prepared:
+            if p is None:
+                out.append(None)
+                continue
+            if status[j] != 0:
+                out.append(None)
+            else:
+                # the same two linear maps for the samples outside the aligned slice (the reference
+                # rescales the whole read, align_signal.py:73)
+                for f in fits:
+                    p.read.normalized_signal = (p.read.normalized_signal - f[j, 1]) / f[j, 0]
+                out.append((p.apx, self._alignment_rows(p, events[batch.ref_off[j]:batch.ref_off[j + 1]])))
+            j += 1
+        return out
+
     # ---- SNP scoring -----------------------------------------------------------------------------
     def _log_likelihood_batch(self, reference, reads):
         """Stages shared by both modes: -> (live prepared reads, FlatBatch, ll (sum R, 4), status)."""

@@ -2,7 +2,8 @@
 
 ``normalize_reads`` (global median/MAD + clip) and ``tweak_signal_normalization`` (spline through
 (event mean, expected level) pairs) are host steps adjacent to the GPU path; they use the same
-numpy/scipy calls as the reference so their results are identical.  fast5 loading needs h5py and is
+numpy/scipy calls as the reference so their results are identical.  ``normalize_reads_device`` is the
+same normalisation as a device kernel (what the workflows call).  fast5 loading needs h5py and is
 imported lazily (no fast5 data exists offline)."""
 import numpy
 from scipy import interpolate
@@ -76,6 +77,29 @@ class Read:
         spread = numpy.median(abs(pooled - centre))
         for r in reads:
             r.normalized_signal = numpy.clip((r.raw_signal - centre) / spread, -5, 5)
+
+    @staticmethod
+    def normalize_reads_device(reads, per_read=False, context=None):
+        """``normalize_reads`` on the GPU (``nvk_normalize_groups_dev``: exact radix selection for the
+        two medians, then the clip): one centre and scale for the whole list, or, with ``per_read``,
+        one per read — what ``align_signal`` does by calling ``normalize_reads([read])`` per read
+        (align_signal.py:54).  Results are identical to ``normalize_reads``."""
+        if not reads:
+            return
+        import torch
+        from . import _lib
+        from .device import normalize_groups_dev
+        context = context or _lib.default_context()
+        device = torch.device('cuda', context.device)
+        raws = [numpy.ascontiguousarray(r.raw_signal, dtype=float) for r in reads]
+        bounds = numpy.zeros(len(raws) + 1, dtype=numpy.int64)
+        numpy.cumsum([x.size for x in raws], out=bounds[1:])
+        groups = bounds if per_read else bounds[[0, -1]]
+        raw = torch.from_numpy(numpy.concatenate(raws)).to(device)
+        out, _ = normalize_groups_dev(context, raw, torch.from_numpy(numpy.ascontiguousarray(groups)).to(device))
+        host = out.cpu().numpy()
+        for j, r in enumerate(reads):
+            r.normalized_signal = host[bounds[j]:bounds[j + 1]].copy()
 
     def tweak_signal_normalization(self, alignment, expected_means):
         """Re-normalise the read against the pore model (reference behaviour: read.py:83-94).
