@@ -104,6 +104,80 @@ __global__ __launch_bounds__(NT) void normalize_groups_kernel(int64_t n_groups, 
   }
 }
 
+// ---- one large group (estimate_snps: every sample of every read): the same selection spread over
+// the whole chip.  State lives in device memory so that the 8 x (histogram, pick) passes of a
+// selection need no host round trip.
+struct SelState {
+  unsigned long long prefix;
+  long long rank;
+  double centre;
+  double vals[4];          // results of the selections: median hi/lo, MAD hi/lo
+  unsigned int hist[256];
+};
+
+template <int MODE>
+__global__ __launch_bounds__(NT) void big_hist_kernel(const double *x, int64_t n, int pass, SelState *st) {
+  __shared__ unsigned int hist[256];
+  for (int q = threadIdx.x; q < 256; q += NT) hist[q] = 0u;
+  __syncthreads();
+  const int shift = 56 - 8 * pass;
+  const unsigned long long mask = pass ? (~0ull << (shift + 8)) : 0ull;
+  const unsigned long long prefix = st->prefix;
+  const double centre = st->centre;
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+    const double v = MODE ? fabs(x[i] - centre) : x[i];
+    const unsigned long long k = key_of(v);
+    if ((k & mask) == prefix) atomicAdd(&hist[(unsigned)(k >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  for (int q = threadIdx.x; q < 256; q += NT)
+    if (hist[q]) atomicAdd(&st->hist[q], hist[q]);
+}
+
+// one thread: the bucket that holds the wanted rank; after the last pass the key is complete
+__global__ void big_pick_kernel(int pass, int slot, SelState *st) {
+  const int shift = 56 - 8 * pass;
+  long long r = st->rank;
+  int b = 0;
+  for (; b < 255; b++) {
+    if (r < (long long)st->hist[b]) break;
+    r -= st->hist[b];
+  }
+  st->prefix |= (unsigned long long)b << shift;
+  st->rank = r;
+  for (int q = 0; q < 256; q++) st->hist[q] = 0u;
+  if (pass == 7) st->vals[slot] = val_of(st->prefix);
+}
+
+// one thread: start a selection / combine the middle values (what = 0: begin selection of `rank`;
+// 1: centre = median from vals[0..1]; 2: scale from vals[2..3] and publish both)
+__global__ void big_step_kernel(int what, long long rank, int even, SelState *st, double *centre_scale) {
+  if (what == 0) {
+    st->prefix = 0ull;
+    st->rank = rank;
+  } else if (what == 1) {
+    st->centre = even ? (st->vals[1] + st->vals[0]) / 2 : st->vals[0];
+  } else {
+    const double scale = even ? (st->vals[3] + st->vals[2]) / 2 : st->vals[2];
+    st->vals[2] = scale;
+    if (centre_scale) {
+      centre_scale[0] = st->centre;
+      centre_scale[1] = scale;
+    }
+  }
+}
+
+__global__ __launch_bounds__(NT) void big_clip_kernel(const double *x, int64_t n, const SelState *st,
+                                                     double *out) {
+  const double centre = st->centre, scale = st->vals[2];
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+    double v = (x[i] - centre) / scale;
+    v = (v < -5.0) ? -5.0 : v;
+    v = (v > 5.0) ? 5.0 : v;
+    out[i] = v;
+  }
+}
+
 // ---- numpy's pairwise summation (numpy/_core/src/umath/loops_utils.h.src, @TYPE@_pairwise_sum) ------
 __device__ double np_block_sum(const double *a, int64_t n) {  // n <= 128
   if (n < 8) {
@@ -244,6 +318,43 @@ extern "C" int nvk_normalize_groups_dev(nvk_ctx *ctx, int64_t n_groups, const do
   }
   if (n_groups == 0) return NVK_OK;
   NVK_HIP(hipSetDevice(ctx->device));
+  if (n_groups == 1) {
+    // one group: its size decides between one block and the whole chip
+    int64_t off[2];
+    NVK_HIP(hipMemcpyAsync(off, grp_off, sizeof(off), hipMemcpyDeviceToHost, ctx->stream));
+    NVK_HIP(hipStreamSynchronize(ctx->stream));
+    const int64_t n = off[1] - off[0];
+    if (n > (1 << 16)) {
+      int rc = nvk_ws_reserve(ctx, WS_MISC, 256 + sizeof(SelState));
+      if (rc) return rc;
+      // (the first 256 bytes of WS_MISC are the counters / totals of the alignment launchers)
+      SelState *st = (SelState *)((char *)ctx->ws[WS_MISC] + 256);
+      NVK_HIP(hipMemsetAsync(st, 0, sizeof(SelState), ctx->stream));
+      const double *x = raw + off[0];
+      const unsigned blocks = (unsigned)(ctx->num_cus * 8);
+      const int even = (n & 1) ? 0 : 1;
+      TimerScope ts(ctx, NVK_K_RENORM);
+      for (int mode = 0; mode < 2; mode++) {
+        for (int which = 0; which < 1 + even; which++) {
+          hipLaunchKernelGGL(big_step_kernel, dim3(1), dim3(1), 0, ctx->stream, 0,
+                             (long long)(which == 0 ? n / 2 : n / 2 - 1), even, st, (double *)nullptr);
+          for (int pass = 0; pass < 8; pass++) {
+            if (mode == 0)
+              hipLaunchKernelGGL(big_hist_kernel<0>, dim3(blocks), dim3(NT), 0, ctx->stream, x, n, pass, st);
+            else
+              hipLaunchKernelGGL(big_hist_kernel<1>, dim3(blocks), dim3(NT), 0, ctx->stream, x, n, pass, st);
+            hipLaunchKernelGGL(big_pick_kernel, dim3(1), dim3(1), 0, ctx->stream, pass, 2 * mode + which, st);
+          }
+        }
+        hipLaunchKernelGGL(big_step_kernel, dim3(1), dim3(1), 0, ctx->stream, 1 + mode, 0ll, even, st,
+                           centre_scale);
+      }
+      hipLaunchKernelGGL(big_clip_kernel, dim3(blocks), dim3(NT), 0, ctx->stream, x, n, st, out + off[0]);
+      NVK_HIP(hipGetLastError());
+      NVK_HIP(hipStreamSynchronize(ctx->stream));
+      return NVK_OK;
+    }
+  }
   {
     TimerScope ts(ctx, NVK_K_RENORM);
     const unsigned blocks = (unsigned)(n_groups < 65535 * 16 ? n_groups : 65535 * 16);

@@ -42,6 +42,22 @@ def test_normalize_groups_equals_numpy(env):
         assert np.array_equal(out[off[j]:off[j + 1]], want, equal_nan=True), j
 
 
+@pytest.mark.parametrize('n', [65537, 200000, 300001])
+def test_normalize_one_large_group_equals_numpy(env, n):
+    """one group above 64 k samples takes the chip-wide selection (estimate_snps: all reads pooled)"""
+    from nadavca_amd.device import normalize_groups_dev
+    rng = np.random.default_rng(n)
+    g = np.round(rng.normal(90, 12, n)) if n % 2 else rng.normal(90, 12, n)
+    pad = rng.normal(0, 1, 5)  # the group need not start at the buffer's first sample
+    raw = np.concatenate([pad, g])
+    out, cs = normalize_groups_dev(env['ctx'], _up(env, raw, np.float64), _up(env, [5, 5 + n], np.int64))
+    out, cs = out.cpu().numpy(), cs.cpu().numpy()
+    centre = np.median(g)
+    scale = np.median(abs(g - centre))
+    assert cs[0, 0] == centre and cs[0, 1] == scale
+    assert np.array_equal(out[5:], np.clip((g - centre) / scale, -5, 5))
+
+
 def test_normalize_reads_device_matches_reference_fixture():
     """G5: Read.normalize_reads of the reference on the fixture's reads (one centre/scale for all)."""
     from est_fixture import EstimatorFixture

@@ -45,3 +45,41 @@ def timed(name, fn):
 timed('get_refined_alignments', lambda: est.get_refined_alignments(reads))
 timed('estimate_probabilities (consensus)', lambda: est.estimate_probabilities(genome, reads))
 timed('estimate_probabilities_independent', lambda: est.estimate_probabilities_independent(genome, reads))
+
+
+# ---- align_signal's loop: device-resident (the product) vs the same rounds through the host ----------
+def host_loop():
+    from scipy.stats import linregress
+    res = est.get_refined_alignments(reads)
+    for r in range(3):
+        if r % 2 == 0:
+            for read, (apx, al) in zip(reads, res):
+                bases = [{'A': 0, 'C': 1, 'G': 2, 'T': 3}[x] for x in apx.reference_part]
+                expected = np.array(model.get_expected_signal(bases, [], []))
+                means = [np.mean(read.normalized_signal[s:e]) for _, s, e in al]
+                slope, intercept = linregress(expected, means)[:2]
+                read.normalized_signal = (read.normalized_signal - intercept) / slope
+        else:
+            res = est.get_refined_alignments(reads)
+    return res
+
+
+def fresh():
+    Read.normalize_reads(reads)
+
+
+fresh()
+timed('align+renorm loop, rounds on the host', host_loop)
+fresh()
+timed('align+renorm loop, device-resident', lambda: est.refine_and_renormalize(reads, 3))
+t = time.perf_counter(); Read.normalize_reads(reads); th = time.perf_counter() - t
+Read.normalize_reads_device(reads)
+t = time.perf_counter(); Read.normalize_reads_device(reads); td = time.perf_counter() - t
+print('normalize_reads (one group, %d samples): host %.1f ms, device %.1f ms (with H2D/D2H)' % (
+    sum(len(r.raw_signal) for r in reads), th * 1e3, td * 1e3))
+t = time.perf_counter()
+for r in reads:
+    Read.normalize_reads([r])
+th = time.perf_counter() - t
+t = time.perf_counter(); Read.normalize_reads_device(reads, per_read=True); td = time.perf_counter() - t
+print('normalize_reads per read: host %.1f ms, device %.1f ms (with H2D/D2H)' % (th * 1e3, td * 1e3))
