@@ -202,8 +202,11 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
   double *ring = etab + ETN;
   double *hist = ring + g.SR;                                   // reverse sweep: suffix values
   double2 *hist2 = reinterpret_cast<double2 *>(ring + g.SR);   // forward sweep: (prefix, path score)
-  int *ghist = reinterpret_cast<int *>(hist2 + (size_t)g.H * 64);
-  int *s_read = ghist + (size_t)g.H * 64;
+  // entry H*64 of both arrays is a permanent zero: a lane whose predecessor cell lies outside the
+  // predecessor's band reads it instead of masking what it read (one select on the index instead of
+  // one per loaded register)
+  int *ghist = reinterpret_cast<int *>(hist2 + (size_t)g.H * 64 + 1);
+  int *s_read = ghist + (size_t)g.H * 64 + 1;
 
   const int lane = threadIdx.x;
   const int H = g.H, RM = g.SR - 1;
@@ -213,6 +216,11 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
 
   for (int q = lane; q < g.SR; q += 64) ring[q] = 0.0;
   dens::fill_table(etab, lane, 64);
+  const int HZ = H * 64;
+  if (lane == 0) {
+    hist2[HZ] = make_double2(0.0, 0.0);
+    ghist[HZ] = 0;
+  }
 
   while (true) {
     __syncthreads();
@@ -284,7 +292,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
       Scale sc{0, 0, 0};
       double e = density(ring[i & RM], mean, ac2, mc2, 0, etab);
       int su = 0;
-      bool init_live = true;  // (uniform) the last row is still being swept
+      int init_live = 1;  // (uniform, a scalar register) the last row is still being swept
 
       for (int u = 0; u < n_steps; ++u) {
         const int t = t_max - u;
@@ -316,7 +324,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
           nx = revl[max(r - 64, 0)];
           while (r_old >= 0 && __builtin_amdgcn_readlane(r, r_old & 63) != r_old) r_old--;
           i_old = __builtin_amdgcn_readlane(i, r_old & 63);
-          init_live = init_live && (__builtin_amdgcn_readlane(r, top & 63) == top);
+          init_live &= (__builtin_amdgcn_readlane(r, top & 63) == top) ? 1 : 0;
         }
         if (r_old >= 0) {
           const int need_min = i_old - 1;
@@ -332,9 +340,11 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
         }
         // LDS reads first: the neighbour's value and the sample of the next step's density
         // the neighbour's value is D = gap + mel steps old: slot (su - D) mod H
-        const int hs = (int)min((unsigned)(su - D), (unsigned)(su - D + H)) * 64 + ((lane + 1) & 63);
+        const int j = i + melr;
+        int hs = (int)min((unsigned)(su - D), (unsigned)(su - D + H)) * 64 + ((lane + 1) & 63);
+        hs = (j >= pbs && j <= pbe) ? hs : 2 * HZ;  // outside the predecessor's band: the zero entry
         const double xn = ring[(i - 1) & RM];
-        double pv = hist[hs];
+        const double pv = hist[hs];
         // scalar shifts that bring a neighbour value from D steps ago to the current scale
         // a rescale lies between the step a neighbour value was produced at and now?  (rare, uniform)
         const bool sh_any = (age < c + MEL) && (u >= RS) && (sc.d_last != 0);
@@ -343,8 +353,6 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
         const bool active = (i <= hi) && (i >= bs);
         double P = emission_product<MEL>(e, e1, e2, e3);
         P = (melr == 0) ? 1.0 : P;
-        const int j = i + melr;
-        pv = (j >= pbs && j <= pbe) ? pv : 0.0;
         double t1 = P * pv;
         if (sh_any) {  // the value is D steps old; the last mel of those shifts are in the densities of P
           asm volatile("");
@@ -436,8 +444,8 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
       Scale sc{0, 0, 0};
       double e = density(ring[(i - 1) & RM], mean, ac2, mc2, 0, etab);
       int su = 0;
-      bool init_live = true;  // (uniform) row 0 is still being swept
-      bool top_live = (top < 64); // (uniform) the last row has been started
+      int init_live = 1;  // (uniform, scalar registers) row 0 is still being swept
+      int top_live = (top < 64) ? 1 : 0;  // the last row has been started
 
       double cur_v[PF];
 #pragma unroll
@@ -482,8 +490,8 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
               nx = fwdl[min(r + 64, top)];  // all lanes, see the reverse sweep
               while (r_old < T && __builtin_amdgcn_readlane(r, r_old & 63) != r_old) r_old++;
               i_old = __builtin_amdgcn_readlane(i, r_old & 63);
-              init_live = init_live && (__builtin_amdgcn_readfirstlane(r) == 0);
-              top_live = (__builtin_amdgcn_readlane(r, top & 63) == top);
+              init_live &= (__builtin_amdgcn_readfirstlane(r) == 0) ? 1 : 0;
+              top_live = (__builtin_amdgcn_readlane(r, top & 63) == top) ? 1 : 0;
             }
             if (r_old < T) {
               const int need_max = i_old;
@@ -498,7 +506,9 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
               }
             }
             // LDS reads first: the neighbour's values and the sample of the next step's density
-            const int hs = (int)min((unsigned)(su - D), (unsigned)(su - D + H)) * 64 + ((lane - 1) & 63);
+            const int j = i - melr;
+            int hs = (int)min((unsigned)(su - D), (unsigned)(su - D + H)) * 64 + ((lane - 1) & 63);
+            hs = (j >= pbs && j <= pbe) ? hs : HZ;  // outside the predecessor's band: the zero entry
             const double xn = ring[i & RM];
             const double2 hv = hist2[hs];
             const int Gin = ghist[hs];
@@ -509,11 +519,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
             const bool in_band = active && (i >= bs);
             double P = emission_product<MEL>(e, e1, e2, e3);
             P = (melr == 0) ? 1.0 : P;
-            const int j = i - melr;
-            const bool ok = (j >= pbs) && (j <= pbe);
-            double pv = hv.x, dv = hv.y;
-            pv = ok ? pv : 0.0;
-            dv = ok ? dv : 0.0;
+            const double pv = hv.x, dv = hv.y;
             double t1 = P * pv;
             if (sh_any) {  // see the reverse sweep
               asm volatile("");
@@ -721,7 +727,7 @@ int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadM
     const int H = c + mel > 0 ? c + mel : 1;
     int SR = 256;
     while (SR < 64 * c + CH) SR <<= 1;
-    size_t lds = (size_t)ETN * 8 + (size_t)SR * 8 + (size_t)H * 64 * 20 + 16;
+    size_t lds = (size_t)ETN * 8 + (size_t)SR * 8 + (size_t)H * 64 * 20 + 20 + 16;  // + the zero entry
     if (lds > 160 * 1024) return NVK_ERR_UNSUPPORTED;
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu > 16) per_cu = 16;
