@@ -79,7 +79,10 @@ struct __attribute__((aligned(16))) Lane3 {
   int32_t bs;        // band start of the lane's row
   int32_t end;       // forward: band end `be`; reverse: span end `hi` (with i + mel <= N folded in)
   int32_t lo;        // forward: span start (with i - mel >= 0 folded in); reverse: unused
-  int32_t pbs, pbe;  // band of the row the lane receives from (empty for the sweep's first row)
+  int32_t pA, pW;    // band [pbs, pbe] of the row the lane receives from, as the one-compare test
+                     // (unsigned)(i - pA) <= pW for "the predecessor cell i -/+ mel lies in it":
+                     // pA = pbs + mel (forward) or pbs - mel (reverse), pW = pbe - pbs; the sweep's
+                     // first row has no predecessor: pA = 2^30, pW = 0
   int32_t mg;        // min event length of the applied step | gap << 4 | adv << 12, where gap is the
                      // time offset between this row and the row it receives from (the neighbour's value
                      // is gap + mel steps old) and adv the offset between this row and the lane's
@@ -139,22 +142,22 @@ __global__ __launch_bounds__(256) void lane3_kernel(const ReadMeta *metas, const
     if (r > 0) {
       const RowParam p = rw[r - 1];
       set_density_consts(f, p);
-      f.pbs = p.bs; f.pbe = p.be;
+      f.pA = p.bs + p.mel; f.pW = p.be - p.bs;
       f.lo = max(o.lo, p.mel);
       f.mg = lane3_pack(p.mel, o.off - p.off, adv_f);
     } else {
-      f.mean = 0.0; f.ac = 0.0; f.mc = 0.0; f.mg = lane3_pack(0, 1, 0); f.pbs = 0; f.pbe = -1;
+      f.mean = 0.0; f.ac = 0.0; f.mc = 0.0; f.mg = lane3_pack(0, 1, 0); f.pA = 0x40000000; f.pW = 0;
     }
     // reverse: applies step r -> r+1
     set_density_consts(b, o);
     b.bs = o.bs; b.lo = 0;
     if (r < top) {
       const RowParam q = rw[r + 1];
-      b.pbs = q.bs; b.pbe = q.be;
+      b.pA = q.bs - o.mel; b.pW = q.be - q.bs;
       b.end = min(o.hi, N - o.mel);
       b.mg = lane3_pack(o.mel, q.off - o.off, adv_b);
     } else {
-      b.pbs = 0; b.pbe = -1;
+      b.pA = 0x40000000; b.pW = 0;
       b.end = o.hi;
       b.mg = lane3_pack(o.mel, 1, adv_b);
     }
@@ -164,11 +167,14 @@ __global__ __launch_bounds__(256) void lane3_kernel(const ReadMeta *metas, const
   }
 }
 
+// (also sets the lane's read index into the history ring: the neighbour's value is D = gap + mel
+// steps old, i.e. in slot (su - D) mod H)
 #define TAKE_LANE(l)                                                                   \
   do {                                                                                 \
     mean = (l).mean; ac2 = (l).ac; mc2 = (l).mc; melr = (l).mg & 15;                   \
     D = (((l).mg >> 4) & 255) + melr;                                                  \
-    bs = (l).bs; pbs = (l).pbs; pbe = (l).pbe;                                         \
+    bs = (l).bs; pA = (l).pA; pW = (l).pW;                                             \
+    ra = (int)min((unsigned)(su - D), (unsigned)(su - D + H)) * 64 + nb;               \
   } while (0)
 
 template <int MEL>
@@ -221,6 +227,13 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
     hist2[HZ] = make_double2(0.0, 0.0);
     ghist[HZ] = 0;
   }
+  // per-lane constants kept in vector registers (the compiler would otherwise rebuild them from scalars
+  // with one or two VOP3 instructions at every use): byte offsets of the lane inside a history slot and
+  // the indices of the zero entry
+  unsigned char *histb = reinterpret_cast<unsigned char *>(hist2);
+  unsigned char *ghistb = reinterpret_cast<unsigned char *>(ghist);
+  int lane16 = lane * 16, lane8 = lane * 8, HZv = HZ, HZ2v = 2 * HZ;
+  asm volatile("" : "+v"(lane16), "+v"(lane8), "+v"(HZv), "+v"(HZ2v));
 
   while (true) {
     __syncthreads();
@@ -263,10 +276,13 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
       // Lanes without a row keep bs = hi = -big: never active, never finished.  For the other
       // rows `hi` already folds the "predecessor column exists" test (i + mel <= N).
       double mean = 0, ac2 = 0, mc2 = 0;
-      int bs = -0x40000000, hi = -0x40000000, pbs = 0, pbe = -1, melr = 0, D = 1;
+      int bs = -0x40000000, hi = -0x40000000, pA = 0x40000000, pW = 0, melr = 0, D = 1;
+      int su = 0;                       // history slot written at this step
+      const int nb = (lane + 1) & 63;   // the lane the values come from
+      int ra = (H - 1) * 64 + nb;       // read index into the history ring, advanced with su
       bool is_init = false;
       Lane3 nx;  // the lane's next row (r - 64), fetched one row ahead
-      nx.mean = nx.ac = nx.mc = 0.0; nx.bs = nx.end = nx.lo = nx.pbs = nx.pbe = nx.mg = 0;
+      nx.mean = nx.ac = nx.mc = 0.0; nx.bs = nx.end = nx.lo = nx.pA = nx.pW = nx.mg = 0;
       int i = t_max;
       if (r >= 0) {
         const Lane3 cu = revl[r];
@@ -291,7 +307,6 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
       __syncthreads();
       Scale sc{0, 0, 0};
       double e = density(ring[i & RM], mean, ac2, mc2, 0, etab);
-      int su = 0;
       int init_live = 1;  // (uniform, a scalar register) the last row is still being swept
 
       for (int u = 0; u < n_steps; ++u) {
@@ -340,9 +355,8 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
         }
         // LDS reads first: the neighbour's value and the sample of the next step's density
         // the neighbour's value is D = gap + mel steps old: slot (su - D) mod H
-        const int j = i + melr;
-        int hs = (int)min((unsigned)(su - D), (unsigned)(su - D + H)) * 64 + ((lane + 1) & 63);
-        hs = (j >= pbs && j <= pbe) ? hs : 2 * HZ;  // outside the predecessor's band: the zero entry
+        // outside the predecessor's band: the zero entry
+        const int hs = ((unsigned)(i - pA) <= (unsigned)pW) ? ra : HZ2v;
         const double xn = ring[(i - 1) & RM];
         const double pv = hist[hs];
         // scalar shifts that bring a neighbour value from D steps ago to the current scale
@@ -373,7 +387,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
           asm volatile("");
           if (o != 0.0) kmax = max(kmax, __builtin_amdgcn_frexp_exp(o) - sc.L);
         }
-        hist[su * 64 + lane] = o;
+        *reinterpret_cast<double *>(histb + (su * 512 + lane8)) = o;
         spill_v[(size_t)(t - t_min) * 64 + lane] = o;
         if (age == 0) {  // the scale only moves on these steps
           if (lane == 0) spill_L[u >> RSH] = sc.L;
@@ -390,6 +404,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
         e3 = e2; e2 = e1; e1 = e;
         e = density_end(dn, sc.d_next);
         su = (su + 1 == H) ? 0 : su + 1;
+        ra = (int)min((unsigned)(ra + 64), (unsigned)(ra + 64 - HZ));
         WAVE_SYNC();
       }
       K = __builtin_amdgcn_readfirstlane(kmax);
@@ -406,10 +421,13 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
       // Lanes without a row keep lo = be = +big: never active, never finished.  For the other rows
       // `lo` already folds the "predecessor column exists" test (i - mel >= 0).
       double mean = 0, ac2 = 0, mc2 = 0;
-      int bs = 0, be = 0x40000000, lo = 0x40000000, pbs = 0, pbe = -1, melr = 0, D = 1;
+      int bs = 0, be = 0x40000000, lo = 0x40000000, pA = 0x40000000, pW = 0, melr = 0, D = 1;
+      int su = 0;
+      const int nb = (lane - 1) & 63;
+      int ra = (H - 1) * 64 + nb;
       bool is_init = false;
       Lane3 nx;  // the lane's next row (r + 64), fetched one row ahead
-      nx.mean = nx.ac = nx.mc = 0.0; nx.bs = nx.end = nx.lo = nx.pbs = nx.pbe = nx.mg = 0;
+      nx.mean = nx.ac = nx.mc = 0.0; nx.bs = nx.end = nx.lo = nx.pA = nx.pW = nx.mg = 0;
       int i = t_min - 64 * c;
       if (r < T) {
         const Lane3 cu = fwdl[r];
@@ -443,7 +461,6 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
       __syncthreads();
       Scale sc{0, 0, 0};
       double e = density(ring[(i - 1) & RM], mean, ac2, mc2, 0, etab);
-      int su = 0;
       int init_live = 1;  // (uniform, scalar registers) row 0 is still being swept
       int top_live = (top < 64) ? 1 : 0;  // the last row has been started
 
@@ -506,9 +523,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
               }
             }
             // LDS reads first: the neighbour's values and the sample of the next step's density
-            const int j = i - melr;
-            int hs = (int)min((unsigned)(su - D), (unsigned)(su - D + H)) * 64 + ((lane - 1) & 63);
-            hs = (j >= pbs && j <= pbe) ? hs : HZ;  // outside the predecessor's band: the zero entry
+            const int hs = ((unsigned)(i - pA) <= (unsigned)pW) ? ra : HZv;  // else: the zero entry
             const double xn = ring[i & RM];
             const double2 hv = hist2[hs];
             const int Gin = ghist[hs];
@@ -569,8 +584,8 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
                 fthr = dpv * ((double)abs(__builtin_amdgcn_frexp_exp(dpv) - Gd) * 0x1.0p-52);
               }
             }
-            hist2[su * 64 + lane] = make_double2(o, dpv);
-            ghist[su * 64 + lane] = Gd;
+            *reinterpret_cast<double2 *>(histb + (su * 1024 + lane16)) = make_double2(o, dpv);
+            *reinterpret_cast<int *>(ghistb + (su * 256 + (lane16 >> 2))) = Gd;
             if ((u & 31) == 31 || u == n_steps - 1) {
               bp[(size_t)(u >> 5) * 64 + lane] = bits << (31 - (u & 31));
               bits = 0;
@@ -589,6 +604,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
             e3 = e2; e2 = e1; e1 = e;
             e = density_end(dn, sc.d_next);
             su = (su + 1 == H) ? 0 : su + 1;
+            ra = (int)min((unsigned)(ra + 64), (unsigned)(ra + 64 - HZ));
             WAVE_SYNC();
           }
         }
