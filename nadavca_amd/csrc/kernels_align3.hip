@@ -308,8 +308,15 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
       Scale sc{0, 0, 0};
       double e = density(ring[i & RM], mean, ac2, mc2, 0, etab);
       int init_live = 1;  // (uniform, a scalar register) the last row is still being swept
+      int row0_live = (__builtin_amdgcn_readfirstlane(r) == 0) ? 1 : 0;  // lane 0 is on row 0
 
-      for (int u = 0; u < n_steps; ++u) {
+      // two steps per trip (as the forward sweep does with its prefetch depth): the loop-carried
+      // registers rotate by renaming instead of by copies
+      for (int ub = 0; ub < n_steps; ub += 2) {
+#pragma unroll
+      for (int uq = 0; uq < 2; uq++) {
+        const int u = ub + uq;
+        if (u >= n_steps) break;
         const int t = t_max - u;
         // this step's shift was decided at the end of the previous one
         const int age = u & (RS - 1);  // steps since the last rescale step (the scale only moves there)
@@ -340,6 +347,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
           while (r_old >= 0 && __builtin_amdgcn_readlane(r, r_old & 63) != r_old) r_old--;
           i_old = __builtin_amdgcn_readlane(i, r_old & 63);
           init_live &= (__builtin_amdgcn_readlane(r, top & 63) == top) ? 1 : 0;
+          row0_live = (__builtin_amdgcn_readfirstlane(r) == 0) ? 1 : 0;
         }
         if (r_old >= 0) {
           const int need_min = i_old - 1;
@@ -383,13 +391,14 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
         // below 2^-53 of it in exact arithmetic too).  Overflow / NaN must never happen.
         suspect |= !(o <= HUGE_V);
         prev = o;
-        if (__builtin_amdgcn_readfirstlane(r) == 0) {  // row 0 lives on lane 0; only its kmax is read
+        if (row0_live) {  // row 0 lives on lane 0; only its kmax is read
           asm volatile("");
           if (o != 0.0) kmax = max(kmax, __builtin_amdgcn_frexp_exp(o) - sc.L);
         }
         *reinterpret_cast<double *>(histb + (su * 512 + lane8)) = o;
         spill_v[(size_t)(t - t_min) * 64 + lane] = o;
         if (age == 0) {  // the scale only moves on these steps
+          asm volatile("");  // (a scalar branch first: the lane test need not run at every step)
           if (lane == 0) spill_L[u >> RSH] = sc.L;
         }
         // ---- rescale decision for the next step, then the next step's density
@@ -406,6 +415,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
         su = (su + 1 == H) ? 0 : su + 1;
         ra = (int)min((unsigned)(ra + 64), (unsigned)(ra + 64 - HZ));
         WAVE_SYNC();
+      }
       }
       K = __builtin_amdgcn_readfirstlane(kmax);
       if (K == -0x40000000) K = 0;
@@ -531,7 +541,9 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
             const DensHalf dn = density_begin(xn, mean, ac2, mc2, etab);
             // ---- the cell (r, i): out = P * pred[i - mel] + e(s[i-1]) * out[i - 1]
             const bool active = (i >= lo) && (i <= be);
-            const bool in_band = active && (i >= bs);
+            // (i >= bs is only needed on the rare paths below: outside the band the posterior is zero by
+            // itself, see `post`)
+#define IN_BAND (active && (i >= bs))
             double P = emission_product<MEL>(e, e1, e2, e3);
             P = (melr == 0) ? 1.0 : P;
             const double pv = hv.x, dv = hv.y;
@@ -544,7 +556,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
             o = active ? o : 0.0;
             if (init_live) {
               asm volatile("");
-              if (is_init) o = in_band ? ldexp(1.0, sc.L) : 0.0;
+              if (is_init) o = IN_BAND ? ldexp(1.0, sc.L) : 0.0;
             }
             suspect |= !(o <= HUGE_V);
             prev = o;
@@ -553,7 +565,11 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
             const int ur = n_steps - 1 - u;  // the reverse sweep's step for this anti-diagonal
             if ((ur & (RS - 1)) == RS - 1 || u == 0) Lrev = sL[ur >> RSH];
             const int kap = -(sc.L + K) - Lrev;  // scalar
-            const double post = in_band ? ldexp(o * suf, kap) : 0.0;
+            // No band test here: a cell of the lane's warm-up (lo <= i < bs) has suf == 0, because the
+            // reverse sweep's lane was idle at this (step, lane) — it leaves row r at bs and the planner
+            // keeps its next row (r - 64) from reaching back into [lo, be] of row r — and beyond `be`
+            // o is 0.  (A violation would show up in the row-mass check.)
+            const double post = ldexp(o * suf, kap);
             rsum += post;
             // ---- path step (node.cpp:52-91): running maximum of the previous row, strict '>' at the
             // resolution of the reference's log-doubles (xm::gt_tol): margin = best * |exponent| * 2^-52
@@ -577,7 +593,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
             if (top_live) {
               asm volatile("");
               const double da = ldexp(dpv, (fbest == 0.0) ? 0 : fG - Gd);
-              if (r == top && in_band && (da - fbest > fthr)) {
+              if (r == top && IN_BAND && (da - fbest > fthr)) {
                 fbest = dpv;
                 fG = Gd;
                 fidx = i;
@@ -587,7 +603,9 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
             *reinterpret_cast<double2 *>(histb + (su * 1024 + lane16)) = make_double2(o, dpv);
             *reinterpret_cast<int *>(ghistb + (su * 256 + (lane16 >> 2))) = Gd;
             if ((u & 31) == 31 || u == n_steps - 1) {
-              bp[(size_t)(u >> 5) * 64 + lane] = bits << (31 - (u & 31));
+              int w = u >> 5;
+              asm volatile("" : "+s"(w));  // keeps the address arithmetic inside the branch
+              bp[(size_t)w * 64 + lane] = bits << (31 - (u & 31));
               bits = 0;
             }
             // refill the prefetch slot just consumed
