@@ -15,7 +15,8 @@
 //   ldexp'ed anyway), and a neighbour value from D steps ago is brought to the current scale by
 //   the (scalar) sum of the shifts of those D steps — zero on most steps, so the ldexp is skipped.
 //   Scaling by powers of two is exact, so as long as nothing leaves the double range the integer
-//   results are those of the exact kernel.  Range guards, per read: a value above 2^900 or NaN; a
+//   results are those of the exact kernel.  Range guards, per read: a value above 2^900 or NaN (tested at
+//   the rescale steps; in between an inf or NaN reaches the row sums below); a
 //   scale move that had to be capped (the wave's largest value collapsed faster than the scale can
 //   follow); and the ROW MASS — every allowed path crosses every row exactly once, so the posterior
 //   mass sum_i prefix[r][i] * suffix[r][i] is the same number for every row, and a flushed cell
@@ -62,6 +63,17 @@ constexpr int DMAX = 900;  // the density exponent (<= ~3) plus the move must st
 constexpr int TARGET = 250; // exponent the largest live value is moved to
 #define HUGE_V 0x1.0p+900
 #define MASS_TOL 1e-9          // allowed relative spread of the rows' posterior mass
+
+// The spill is addressed through a buffer resource: address = resource base (scalar) + scalar byte
+// offset of the step + per-lane byte offset (a constant vector register), so neither the store of the
+// reverse sweep nor the prefetch of the forward sweep needs vector address arithmetic.
+typedef int v2i_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void spill_store(__amdgpu_buffer_rsrc_t rs, int lane8, int step, double v) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i_t, v), rs, lane8, step * 512, 0);
+}
+__device__ __forceinline__ double spill_load(__amdgpu_buffer_rsrc_t rs, int lane8, int step) {
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, lane8, step * 512, 0));
+}
 
 #define WAVE_SYNC()                                        \
   do {                                                     \
@@ -216,7 +228,10 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
 
   const int lane = threadIdx.x;
   const int H = g.H, RM = g.SR - 1;
-  double *spill_v = g.spill_v + (size_t)blockIdx.x * g.spill_stride;
+  // (0x00020000: raw 32-bit data format, no swizzle; the range check is left wide open — the slot's size
+  // bounds every offset by construction)
+  const __amdgpu_buffer_rsrc_t spill_rs = __builtin_amdgcn_make_buffer_rsrc(
+      g.spill_v + (size_t)blockIdx.x * g.spill_stride, 0, 0x7ffffff0, 0x00020000);
   int32_t *spill_L = g.spill_L + (size_t)blockIdx.x * g.L_stride;
   uint32_t *bp = g.bp + (size_t)blockIdx.x * g.bp_stride;
 
@@ -389,20 +404,22 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
         // Cells far off the likely path are thousands of bits below the wave's largest value and
         // flush to zero here; that cannot change any value that matters (their contributions are
         // below 2^-53 of it in exact arithmetic too).  Overflow / NaN must never happen.
-        suspect |= !(o <= HUGE_V);
         prev = o;
         if (row0_live) {  // row 0 lives on lane 0; only its kmax is read
           asm volatile("");
           if (o != 0.0) kmax = max(kmax, __builtin_amdgcn_frexp_exp(o) - sc.L);
         }
         *reinterpret_cast<double *>(histb + (su * 512 + lane8)) = o;
-        spill_v[(size_t)(t - t_min) * 64 + lane] = o;
+        spill_store(spill_rs, lane8, t - t_min, o);
         if (age == 0) {  // the scale only moves on these steps
           asm volatile("");  // (a scalar branch first: the lane test need not run at every step)
           if (lane == 0) spill_L[u >> RSH] = sc.L;
         }
         // ---- rescale decision for the next step, then the next step's density
         if (age == RS - 1) {
+          // (range guard of the values themselves: here only — an inf or NaN between two rescale steps
+          // reaches the posterior sums of its row and fails the row-mass check)
+          suspect |= !(o <= HUGE_V);
           int ex = (o != 0.0) ? __builtin_amdgcn_frexp_exp(o) : -0x40000000;
           int mx = wave_max_i(ex);
           sc.d_next = (mx > -0x40000000) ? min(TARGET - mx, DMAX) : 0;
@@ -476,7 +493,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
 
       double cur_v[PF];
 #pragma unroll
-      for (int q = 0; q < PF; q++) cur_v[q] = spill_v[(size_t)q * 64 + lane];
+      for (int q = 0; q < PF; q++) cur_v[q] = spill_load(spill_rs, lane8, q);
       // The reverse sweep's scale, one value per RS steps, comes through the scalar cache: it is
       // uniform, and a vector load per step would put one more operation on the wait counter that
       // guards the spill prefetch.  The cache was invalidated after the reverse sweep's stores.
@@ -558,7 +575,6 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
               asm volatile("");
               if (is_init) o = IN_BAND ? ldexp(1.0, sc.L) : 0.0;
             }
-            suspect |= !(o <= HUGE_V);
             prev = o;
             // ---- posterior of the cell, on the scale 2^-K:  post = prefix * suffix
             const double suf = cur_v[q];
@@ -609,9 +625,10 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
               bits = 0;
             }
             // refill the prefetch slot just consumed
-            cur_v[q] = spill_v[(size_t)(u + PF) * 64 + lane];
+            cur_v[q] = spill_load(spill_rs, lane8, u + PF);
             // ---- rescale decision for the next step, then the next step's density
             if (age == RS - 1) {
+              suspect |= !(o <= HUGE_V);
               int ex = (o != 0.0) ? __builtin_amdgcn_frexp_exp(o) : -0x40000000;
               int mx = wave_max_i(ex);
               sc.d_next = (mx > -0x40000000) ? min(TARGET - mx, DMAX) : 0;
