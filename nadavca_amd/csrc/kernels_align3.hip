@@ -187,6 +187,7 @@ __global__ __launch_bounds__(256) void lane3_kernel(const ReadMeta *metas, const
     D = (((l).mg >> 4) & 255) + melr;                                                  \
     bs = (l).bs; pA = (l).pA; pW = (l).pW;                                             \
     ra = (int)min((unsigned)(su - D), (unsigned)(su - D + H)) * 64 + nb;               \
+    pm = melr ? 1.0 : 0.0; qm = melr ? 0.0 : 1.0;                                      \
   } while (0)
 
 template <int MEL>
@@ -292,6 +293,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
       // rows `hi` already folds the "predecessor column exists" test (i + mel <= N).
       double mean = 0, ac2 = 0, mc2 = 0;
       int bs = -0x40000000, hi = -0x40000000, pA = 0x40000000, pW = 0, melr = 0, D = 1;
+      double pm = 0.0, qm = 1.0;
       int su = 0;                       // history slot written at this step
       const int nb = (lane + 1) & 63;   // the lane the values come from
       int ra = (H - 1) * 64 + nb;       // read index into the history ring, advanced with su
@@ -389,7 +391,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
         // ---- the cell (r, i): out = P * pred[i + mel] + e(s[i]) * out[i + 1]
         const bool active = (i <= hi) && (i >= bs);
         double P = emission_product<MEL>(e, e1, e2, e3);
-        P = (melr == 0) ? 1.0 : P;
+        if (MEL > 0) P = fma(P, pm, qm);  // (1, 0) on emitting rows, (0, 1) on rows without emission: P or 1
         double t1 = P * pv;
         if (sh_any) {  // the value is D steps old; the last mel of those shifts are in the densities of P
           asm volatile("");
@@ -449,6 +451,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
       // `lo` already folds the "predecessor column exists" test (i - mel >= 0).
       double mean = 0, ac2 = 0, mc2 = 0;
       int bs = 0, be = 0x40000000, lo = 0x40000000, pA = 0x40000000, pW = 0, melr = 0, D = 1;
+      double pm = 0.0, qm = 1.0;
       int su = 0;
       const int nb = (lane - 1) & 63;
       int ra = (H - 1) * 64 + nb;
@@ -562,7 +565,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
             // itself, see `post`)
 #define IN_BAND (active && (i >= bs))
             double P = emission_product<MEL>(e, e1, e2, e3);
-            P = (melr == 0) ? 1.0 : P;
+            if (MEL > 0) P = fma(P, pm, qm);
             const double pv = hv.x, dv = hv.y;
             double t1 = P * pv;
             if (sh_any) {  // see the reverse sweep
