@@ -91,10 +91,13 @@ struct __attribute__((aligned(16))) Lane3 {
   int32_t bs;        // band start of the lane's row
   int32_t end;       // forward: band end `be`; reverse: span end `hi` (with i + mel <= N folded in)
   int32_t lo;        // forward: span start (with i - mel >= 0 folded in); reverse: unused
-  int32_t pA, pW;    // band [pbs, pbe] of the row the lane receives from, as the one-compare test
-                     // (unsigned)(i - pA) <= pW for "the predecessor cell i -/+ mel lies in it":
-                     // pA = pbs + mel (forward) or pbs - mel (reverse), pW = pbe - pbs; the sweep's
-                     // first row has no predecessor: pA = 2^30, pW = 0
+  int32_t pA, pW;    // the cells at which the lane takes a value from its neighbour, as the one-compare
+                     // test (unsigned)(i - pA) <= pW: the lane is inside its own span AND the predecessor
+                     // cell i -/+ mel lies in the band [pbs, pbe] of the row it receives from, i.e. the
+                     // intersection of [lo, be] (reverse: [bs, hi]) with [pbs + mel, pbe + mel] (reverse:
+                     // - mel).  Everywhere else the lane reads the zero entry of the history ring, which
+                     // also keeps its own value at zero outside its span (it starts a row at zero and
+                     // leaves it at the span's end), so no other masking is needed.  Empty: 2^30, 0.
   int32_t mg;        // min event length of the applied step | gap << 4 | adv << 12, where gap is the
                      // time offset between this row and the row it receives from (the neighbour's value
                      // is gap + mel steps old) and adv the offset between this row and the lane's
@@ -154,8 +157,11 @@ __global__ __launch_bounds__(256) void lane3_kernel(const ReadMeta *metas, const
     if (r > 0) {
       const RowParam p = rw[r - 1];
       set_density_consts(f, p);
-      f.pA = p.bs + p.mel; f.pW = p.be - p.bs;
       f.lo = max(o.lo, p.mel);
+      {
+        const int a = max(f.lo, p.bs + p.mel), z = min(o.be, p.be + p.mel);
+        f.pA = (z >= a) ? a : 0x40000000; f.pW = (z >= a) ? z - a : 0;
+      }
       f.mg = lane3_pack(p.mel, o.off - p.off, adv_f);
     } else {
       f.mean = 0.0; f.ac = 0.0; f.mc = 0.0; f.mg = lane3_pack(0, 1, 0); f.pA = 0x40000000; f.pW = 0;
@@ -165,8 +171,11 @@ __global__ __launch_bounds__(256) void lane3_kernel(const ReadMeta *metas, const
     b.bs = o.bs; b.lo = 0;
     if (r < top) {
       const RowParam q = rw[r + 1];
-      b.pA = q.bs - o.mel; b.pW = q.be - q.bs;
       b.end = min(o.hi, N - o.mel);
+      {
+        const int a = max(o.bs, q.bs - o.mel), z = min(b.end, q.be - o.mel);
+        b.pA = (z >= a) ? a : 0x40000000; b.pW = (z >= a) ? z - a : 0;
+      }
       b.mg = lane3_pack(o.mel, q.off - o.off, adv_b);
     } else {
       b.pA = 0x40000000; b.pW = 0;
@@ -354,7 +363,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
               is_init = false;
               e = density(ring[i & RM], mean, ac2, mc2, (age == 0 && u > 0) ? sc.d_last : 0, etab);
             } else {
-              hi = -0x40000000; bs = -0x40000000;
+              hi = -0x40000000; bs = -0x40000000; pA = 0x40000000; pW = 0;
             }
           }
           // Every lane (re)fetches its next row here, not only the lanes that switched: a load under
@@ -389,7 +398,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
         const bool sh_any = (age < c + MEL) && (u >= RS) && (sc.d_last != 0);
         const DensHalf dn = density_begin(xn, mean, ac2, mc2, etab);
         // ---- the cell (r, i): out = P * pred[i + mel] + e(s[i]) * out[i + 1]
-        const bool active = (i <= hi) && (i >= bs);
+#define ACTIVE_R ((i <= hi) && (i >= bs))
         double P = emission_product<MEL>(e, e1, e2, e3);
         if (MEL > 0) P = fma(P, pm, qm);  // (1, 0) on emitting rows, (0, 1) on rows without emission: P or 1
         double t1 = P * pv;
@@ -397,11 +406,10 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
           asm volatile("");
           t1 = ldexp(t1, (age >= melr && age < D) ? sc.d_last : 0);
         }
-        double o = fma(e, prev, t1);
-        o = active ? o : 0.0;
+        double o = fma(e, prev, t1);  // zero outside the lane's span, see Lane3::pA
         if (init_live) {
           asm volatile("");
-          if (is_init) o = active ? ldexp(1.0, sc.L) : 0.0;
+          if (is_init) o = ACTIVE_R ? ldexp(1.0, sc.L) : 0.0;
         }
         // Cells far off the likely path are thousands of bits below the wave's largest value and
         // flush to zero here; that cannot change any value that matters (their contributions are
@@ -531,7 +539,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
                   is_init = false;
                   e = density(ring[(i - 1) & RM], mean, ac2, mc2, (age == 0 && u > 0) ? sc.d_last : 0, etab);
                 } else {
-                  lo = 0x40000000; be = 0x40000000;
+                  lo = 0x40000000; be = 0x40000000; pA = 0x40000000; pW = 0;
                 }
               }
               nx = fwdl[min(r + 64, top)];  // all lanes, see the reverse sweep
@@ -560,10 +568,9 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
             const bool sh_any = (age < c + MEL) && (u >= RS) && (sc.d_last != 0);
             const DensHalf dn = density_begin(xn, mean, ac2, mc2, etab);
             // ---- the cell (r, i): out = P * pred[i - mel] + e(s[i-1]) * out[i - 1]
-            const bool active = (i >= lo) && (i <= be);
-            // (i >= bs is only needed on the rare paths below: outside the band the posterior is zero by
-            // itself, see `post`)
-#define IN_BAND (active && (i >= bs))
+            // (the band test is only needed on the rare paths below: outside the band the posterior is zero
+            // by itself, see `post`, and outside the lane's span its value is, see Lane3::pA)
+#define IN_BAND ((i >= lo) && (i <= be) && (i >= bs))
             double P = emission_product<MEL>(e, e1, e2, e3);
             if (MEL > 0) P = fma(P, pm, qm);
             const double pv = hv.x, dv = hv.y;
@@ -573,7 +580,6 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
               t1 = ldexp(t1, (age >= melr && age < D) ? sc.d_last : 0);
             }
             double o = fma(e, prev, t1);
-            o = active ? o : 0.0;
             if (init_live) {
               asm volatile("");
               if (is_init) o = IN_BAND ? ldexp(1.0, sc.L) : 0.0;
@@ -596,7 +602,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
             // normalised (bestn in [0.5,1), scale G); an incoming score is brought onto that scale
             // before comparing (far below -> 0, far above -> inf, both compare correctly).
             const double dva = ldexp(dv, G - Gin);  // no maximum yet: G = GBIG, any dv > 0 becomes +inf
-            const bool upd = active && (dva - bestn > bthr);
+            const bool upd = (dva - bestn > bthr);  // (dv == 0 outside the span: never an update)
             if (upd) {
               bestn = __builtin_amdgcn_frexp_mant(dv);         // in [0.5, 1)
               G = Gin - __builtin_amdgcn_frexp_exp(dv);        // its scale; -G = true exponent
