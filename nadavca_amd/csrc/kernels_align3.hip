@@ -31,9 +31,26 @@
 //
 // Memory: spill 8 B per cell (+4 B of scale per RS steps) instead of 12 B per cell; no row table in
 // LDS (lane3_kernel prepares per-sweep lane records, a lane fetches its next row one row ahead into
-// registers), so 9.4 KB of LDS and 120 VGPRs give 16 waves per CU.  Launch: reads are handed to the
+// registers), so 9.5 KB of LDS and 126 VGPRs give 16 waves per CU.  Launch: reads are handed to the
 // persistent waves longest first (launch_order); reads whose skew exceeds ALIGN1_C_CAP run in a
 // second launch with larger rings and a longer rescale period.
+//
+// Time mapping: cell (r, i) is computed at step t = i + off[r] with the planner's per-row offsets
+// (RowParam::off, kernels_plan.hip) instead of one skew per read; a lane record carries the row's gap
+// to the row it receives from (the neighbour's value is gap + mel steps old) and its advance over the
+// lane's previous row.
+//
+// What the step does NOT do any more (each was measured): no masks on loaded or
+// computed values — a lane reads a permanent zero entry of the history ring wherever it is outside its
+// own span or the predecessor cell is outside the predecessor's band (one interval per row,
+// Lane3::pA/pW), which keeps its own recurrence at zero by itself, and the spilled suffix is zero
+// outside the band, so the posterior is; no vector address arithmetic for the spill (buffer resource:
+// scalar step offset + constant lane offset) or for the history ring (read index advanced per lane,
+// write address = scalar slot base + constant lane offset); the emission product's row-type select is
+// one FMA with per-row constants; uniform conditions live in scalar registers.  Tried and not kept:
+// 16 or 4 forward steps per loop trip (instruction cache / prefetch depth), the sample of the next
+// density read one step earlier (-0.7 %, but 4 more registers: over 128 with the FMA constants),
+// update bits shifted in with v_addc (inline assembly blocks the scheduler: +1 %).
 #include <math.h>
 
 #include "nvk_internal.h"
