@@ -43,14 +43,15 @@ def cpu_baseline(batch, model, bandwidth, mel, workload, budget_reads_per_core=2
     if hasattr(os, 'sched_getaffinity'):
         cores = max(1, min(cores, len(os.sched_getaffinity(0))))
     cores = int(os.environ.get('NADAVCA_CPU_THREADS', cores))
-    per_core = budget_reads_per_core if workload == 'cfg2_align' else max(8, budget_reads_per_core // 10)
+    per_core = budget_reads_per_core if workload == 'cfg2_align' else (
+        1 if workload == 'cfg5_long' else max(8, budget_reads_per_core // 10))
     n = min(batch.n, cores * per_core)
     cases = batch.cases[:n]
 
     def work(c):
         a = (c['signal'], c['reference'], c['context_before'], c['context_after'],
              c['approximate_alignment'], bandwidth, mel, m)
-        if workload == 'cfg2_align':
+        if workload in ('cfg2_align', 'cfg5_long'):
             o.refine_alignment(*a, True)
         else:
             o.estimate_log_likelihoods(*a, True)
@@ -62,7 +63,7 @@ def cpu_baseline(batch, model, bandwidth, mel, workload, budget_reads_per_core=2
     dt = time.perf_counter() - t0
     return {'value': n / dt, 'unit': 'reads/s', 'cores': cores, 'kind': kind,
             'sample': '%d of the run\'s reads, %s, %d threads, %.1f s wall' % (
-                n, 'refine_alignment(transitions)' if workload == 'cfg2_align' else 'estimate_log_likelihoods(wobbling)',
+                n, 'estimate_log_likelihoods(wobbling)' if workload == 'cfg3_snps' else 'refine_alignment(transitions)',
                 cores, dt),
             'per_core': n / dt / cores}
 
@@ -87,7 +88,9 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--workload', default='cfg2_align', choices=['cfg2_align', 'cfg3_snps'])
+    ap.add_argument('--workload', default='cfg2_align', choices=['cfg2_align', 'cfg3_snps', 'cfg5_long'],
+                    help='cfg2_align (default, the headline), cfg3_snps, cfg5_long (BASELINE config 5 shape: '
+                         '~50k-sample reads, bandwidth 1000; refine_alignment)')
     ap.add_argument('--reads', type=int, default=0, help='reads per GPU per step (default: the config size)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--slots', type=int, default=0)
@@ -125,11 +128,12 @@ def main():
     batch = synthetic.make_batch(n_reads, model, seed=1000 + rank, **wl)
     dbatch = DeviceBatch(batch, device)
     events = torch.zeros((dbatch.total_ref, 2), dtype=torch.int32, device=device)
-    ll = torch.zeros((dbatch.total_ref, 4), dtype=torch.float64, device=device) if args.workload != 'cfg2_align' else None
+    is_align = args.workload in ('cfg2_align', 'cfg5_long')
+    ll = None if is_align else torch.zeros((dbatch.total_ref, 4), dtype=torch.float64, device=device)
     status = torch.zeros(dbatch.n, dtype=torch.int32, device=device)
 
     def step():
-        if args.workload == 'cfg2_align':
+        if is_align:
             refine_alignment_dev(dbatch, bandwidth, mel, km, True, events, status)
         else:
             estimate_log_likelihoods_dev(dbatch, bandwidth, mel, km, True, ll, status)
@@ -162,8 +166,9 @@ def main():
     if rank == 0:
         total_reads = n_reads * world * args.steps
         out = {
-            'metric': 'reads/sec (align_signal, ~4k-sample reads)' if args.workload == 'cfg2_align'
-                      else 'reads/sec (estimate_snps log-likelihoods, ~4k-sample reads)',
+            'metric': {'cfg2_align': 'reads/sec (align_signal, ~4k-sample reads)',
+                       'cfg3_snps': 'reads/sec (estimate_snps log-likelihoods, ~4k-sample reads)',
+                       'cfg5_long': 'reads/sec (align_signal, ~50k-sample reads, wide band)'}[args.workload],
             'value': total_reads / dt, 'unit': 'reads/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1000.0 * dt / args.steps, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
@@ -174,10 +179,10 @@ def main():
                        'band_cells_per_read': round(stats['band_cells'] / n_reads, 1),
                        'reads_redone_exact': stats['reads_redone_exact']},
         }
-        kname = 'align' if args.workload == 'cfg2_align' else 'ell_hyp'
+        kname = 'align' if is_align else 'ell_hyp'
         ms, launches = timing[kname]
         if launches:
-            algo = (dbatch.algorithmic_bytes_align(stats['band_cells']) if args.workload == 'cfg2_align'
+            algo = (dbatch.algorithmic_bytes_align(stats['band_cells']) if is_align
                     else dbatch.algorithmic_bytes_snp(stats['band_cells']))
             sec = ms / 1000.0 / launches
             ach = algo / sec / 1e9
