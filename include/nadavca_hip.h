@@ -225,6 +225,15 @@ int nvk_linfit_rescale_dev(nvk_ctx *ctx, int64_t n_reads, const double *expected
                            const int64_t *ref_off, const int32_t *status, double *signal,
                            const int64_t *sig_off, double *out_fit);
 
+/* replaces scipy.interpolate.splev(x, (t, c, k)) — the evaluation half of
+ * Read.tweak_signal_normalization (/root/reference/nadavca/read.py:94; the fit, splrep, stays on the
+ * host) — for n_groups groups laid end to end: out[i] = spline_g(x[i]) for i in [grp_off[g], grp_off[g+1]),
+ * spline g given by the knots t[knot_off[g] .. knot_off[g+1]) and as many coefficients c[...] as FITPACK
+ * returns them, degree k (1..5), extrapolating outside the knots (ext = 0).  FITPACK's splev.f / fpbspl.f
+ * restated operation for operation: results equal scipy's bit for bit.  out may alias x.  Device pointers. */
+int nvk_splev_groups_dev(nvk_ctx *ctx, int64_t n_groups, const double *x, const int64_t *grp_off,
+                         const double *t, const double *c, const int64_t *knot_off, int k, double *out);
+
 #ifdef __cplusplus
 }
 #endif

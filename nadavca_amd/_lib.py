@@ -61,6 +61,7 @@ SIGNATURES = {
     'nvk_normalize_groups_dev': (_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
     'nvk_event_means_dev': (_int, [_vp, _i64, _i64] + [_vp] * 6),
     'nvk_linfit_rescale_dev': (_int, [_vp, _i64] + [_vp] * 7),
+    'nvk_splev_groups_dev': (_int, [_vp, _i64] + [_vp] * 5 + [_int, _vp]),
 }
 
 _lib = None

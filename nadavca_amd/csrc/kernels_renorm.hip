@@ -4,6 +4,8 @@
 //   nvk_normalize_groups_dev   Read.normalize_reads            nadavca/read.py:68-81
 //   nvk_event_means_dev        the per-event numpy.mean         nadavca/align_signal.py:66-69, read.py:85-86
 //   nvk_linfit_rescale_dev     scipy.stats.linregress + rescale nadavca/align_signal.py:71-73
+//   nvk_splev_groups_dev       scipy.interpolate.splev          nadavca/read.py:94 (the spline tweak's evaluation;
+//                              the fit, FITPACK's splrep, stays on the host)
 //
 // All three are byte/HBM-bound passes over the signal (8 B per sample) — no MFMA, no LDS tiling.
 // Exactness: the medians are exact selections (radix select on the order-preserving integer image of
@@ -308,7 +310,89 @@ __global__ __launch_bounds__(NT) void linfit_rescale_kernel(int64_t n_reads, con
   }
 }
 
+// ---- FITPACK splev (scipy.interpolate.splev, ext = 0): splev.f / fpbspl.f operation for operation ------
+// One block per group (read); the group's knots and coefficients are staged in LDS when they fit.
+constexpr int SPL_LDS = 512;  // knots held in LDS per block
+__global__ __launch_bounds__(NT) void splev_groups_kernel(int64_t n_groups, const double *x,
+                                                         const int64_t *grp_off, const double *t,
+                                                         const double *c, const int64_t *knot_off, int k,
+                                                         double *out) {
+  __shared__ double sh_t[SPL_LDS], sh_c[SPL_LDS];
+  for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+    const int64_t o = grp_off[g], m = grp_off[g + 1] - o;
+    const int64_t ko = knot_off[g];
+    const int n = (int)(knot_off[g + 1] - ko);
+    const int k1 = k + 1, nk1 = n - k1;
+    const double *tt = t + ko, *cc = c + ko;
+    __syncthreads();
+    if (n <= SPL_LDS) {
+      for (int q = threadIdx.x; q < n; q += NT) {
+        sh_t[q] = tt[q];
+        sh_c[q] = cc[q];
+      }
+      tt = sh_t;
+      cc = sh_c;
+    }
+    __syncthreads();
+    if (nk1 < k1) {  // not a spline of degree k: nothing FITPACK would evaluate
+      for (int64_t i = threadIdx.x; i < m; i += NT) out[o + i] = nan("");
+      continue;
+    }
+    for (int64_t i = threadIdx.x; i < m; i += NT) {
+      const double arg = x[o + i];
+      // knot interval: the first l in [k1, nk1) (1-based, as in splev.f) with arg < t(l+1), else nk1
+      int lo = k1, hi = nk1;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (arg < tt[mid]) hi = mid; else lo = mid + 1;  // tt[mid] is t(mid+1)
+      }
+      const int l = lo;
+      // fpbspl: the k+1 non-zero B-splines of degree k at arg, by the stable recurrence
+      double h[6], hh[5];
+      h[0] = 1.0;
+      for (int j = 1; j <= k; j++) {
+        for (int q = 0; q < j; q++) hh[q] = h[q];
+        h[0] = 0.0;
+        for (int q = 1; q <= j; q++) {
+          const double tli = tt[l + q - 1], tlj = tt[l + q - j - 1];
+          if (tli == tlj) {
+            h[q] = 0.0;
+            continue;
+          }
+          const double f = hh[q - 1] / (tli - tlj);
+          h[q - 1] = h[q - 1] + f * (tli - arg);
+          h[q] = f * (arg - tlj);
+        }
+      }
+      double sp = 0.0;
+      for (int j = 0; j < k1; j++) sp = sp + cc[l - k1 + j] * h[j];
+      out[o + i] = sp;
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int nvk_splev_groups_dev(nvk_ctx *ctx, int64_t n_groups, const double *x, const int64_t *grp_off,
+                                    const double *t, const double *c, const int64_t *knot_off, int k,
+                                    double *out) {
+  if (!ctx || n_groups < 0 || k < 1 || k > 5 ||
+      (n_groups > 0 && (!x || !grp_off || !t || !c || !knot_off || !out))) {
+    nvk_set_error("nvk_splev_groups_dev: invalid argument (degree 1..5)");
+    return NVK_ERR_INVALID;
+  }
+  if (n_groups == 0) return NVK_OK;
+  NVK_HIP(hipSetDevice(ctx->device));
+  {
+    TimerScope ts(ctx, NVK_K_RENORM);
+    const unsigned blocks = (unsigned)(n_groups < 65535 * 16 ? n_groups : 65535 * 16);
+    hipLaunchKernelGGL(splev_groups_kernel, dim3(blocks), dim3(NT), 0, ctx->stream, n_groups, x, grp_off, t, c,
+                       knot_off, k, out);
+  }
+  NVK_HIP(hipGetLastError());
+  NVK_HIP(hipStreamSynchronize(ctx->stream));
+  return NVK_OK;
+}
 
 extern "C" int nvk_normalize_groups_dev(nvk_ctx *ctx, int64_t n_groups, const double *raw,
                                         const int64_t *grp_off, double *out, double *centre_scale) {

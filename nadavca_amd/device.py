@@ -143,6 +143,18 @@ def linfit_rescale_dev(dbatch, context, expected, means, status=None):
     return fit
 
 
+def splev_groups_dev(context, x, grp_off, t, c, knot_off, degree, out=None):
+    """``scipy.interpolate.splev`` for groups of samples laid end to end, one spline (its knots ``t`` and
+    coefficients ``c`` between ``knot_off[g]`` and ``knot_off[g+1]``) per group -> values (torch f64)."""
+    import torch
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.check(lib.nvk_splev_groups_dev(context.handle, int(grp_off.numel()) - 1, _dp(x), _dp(grp_off), _dp(t),
+                                        _dp(c), _dp(knot_off), int(degree), _dp(out)), 'nvk_splev_groups_dev')
+    return out
+
+
 def refine_renorm_loop_dev(dbatch, bandwidth, min_event_length, kmer_model, model_transitions,
                            renorm_rounds):
     """The renormalise / re-align loop of ``align_signal`` (align_signal.py:55-80) for a whole batch

@@ -6,8 +6,9 @@ launch over all reads —
     refine_alignment (tweak pre-pass)  -> expected levels -> [host: spline tweak, scipy]
     -> estimate_log_likelihoods -> normalise / strand-flip / per-position sum (consensus kernel)
     -> windowed posterior kernel.
-Nothing numerical runs on the CPU except the scipy spline of ``Read.tweak_signal_normalization``
-(a host step of the reference adjacent to the path, kept bit-identical by using the same call).
+Nothing numerical runs on the CPU except the spline FIT of ``Read.tweak_signal_normalization``
+(FITPACK ``splrep``, a host step of the reference adjacent to the path, the same scipy call); its
+evaluation over the signals is a kernel that restates FITPACK's ``splev`` bit for bit.
 """
 import ctypes as C
 
@@ -188,12 +189,18 @@ class ProbabilityEstimator:
                 self.min_event_length, self.kmer_model, False)
             expected = self.kmer_model.get_expected_signal_batch(
                 [(p.reference_part, p.context_before, p.context_after) for p in live])
+            fitted, splines = [], []
             for p, ev, exp in zip(live, pre, expected):
                 if len(ev) == 0:
                     # the reference would index an empty array here and fail; keep the untweaked signal
                     p.read.tweaked_normalized_signal = p.read.normalized_signal
                     continue
-                p.read.tweak_signal_normalization(numpy.asarray(ev) + p.signal_range[0], exp)
+                # the fit on the host (FITPACK splrep, the reference's call), the evaluation over the
+                # whole signal for all reads in one kernel
+                splines.append(p.read.fit_signal_tweak(numpy.asarray(ev) + p.signal_range[0], exp))
+                fitted.append(p.read)
+            from .read import Read
+            Read.apply_signal_tweaks_device(fitted, splines, context=self.kmer_model.context)
             signals = [p.read.tweaked_normalized_signal for p in live]
         else:
             signals = [p.read.normalized_signal for p in live]

@@ -101,12 +101,13 @@ class Read:
         for j, r in enumerate(reads):
             r.normalized_signal = host[bounds[j]:bounds[j + 1]].copy()
 
-    def tweak_signal_normalization(self, alignment, expected_means):
-        """Re-normalise the read against the pore model (reference behaviour: read.py:83-94).
+    def fit_signal_tweak(self, alignment, expected_means):
+        """The fit of ``tweak_signal_normalization`` -> FITPACK spline ``(t, c, k)``.
+        Re-normalise the read against the pore model (reference behaviour: read.py:83-94).
         For every aligned event (absolute sample range per row of ``alignment``) take the mean of
         ``normalized_signal``; keep the events whose mean is within 1 of the model's expected level;
         fit a smoothing spline (FITPACK ``splrep`` with s = number of points) from observed mean to
-        expected level and apply it to the whole signal -> ``tweaked_normalized_signal``."""
+        expected level; the caller applies it to the whole signal -> ``tweaked_normalized_signal``."""
         signal = self.normalized_signal
         events = numpy.asarray(alignment)[:, :2].astype(numpy.intp).reshape(-1, 2)
         levels = numpy.asarray(expected_means, dtype=float)[:len(events)]
@@ -126,5 +127,39 @@ class Read:
         xs, ys = observed[keep], levels[keep]
         order = numpy.lexsort((ys, xs))
         xs, ys = xs[order], ys[order]
-        knots = interpolate.splrep(xs, ys, s=len(xs))
-        self.tweaked_normalized_signal = interpolate.splev(signal, knots)
+        return interpolate.splrep(xs, ys, s=len(xs))
+
+    def tweak_signal_normalization(self, alignment, expected_means):
+        """``fit_signal_tweak`` + the spline's evaluation over the whole signal (read.py:94), both on the
+        host with the reference's scipy calls; the workflows evaluate on the GPU instead
+        (``apply_signal_tweaks_device``)."""
+        knots = self.fit_signal_tweak(alignment, expected_means)
+        self.tweaked_normalized_signal = interpolate.splev(self.normalized_signal, knots)
+
+    @staticmethod
+    def apply_signal_tweaks_device(reads, splines, context=None):
+        """``tweaked_normalized_signal = splev(normalized_signal, spline)`` for many reads in one kernel
+        (``nvk_splev_groups_dev``: FITPACK's evaluation restated operation for operation, results equal
+        scipy's).  ``splines``: one ``(t, c, k)`` per read, as ``fit_signal_tweak`` returns them."""
+        if not reads:
+            return
+        import torch
+        from . import _lib
+        from .device import splev_groups_dev
+        context = context or _lib.default_context()
+        device = torch.device('cuda', context.device)
+        sigs = [numpy.ascontiguousarray(r.normalized_signal, dtype=float) for r in reads]
+        bounds = numpy.zeros(len(sigs) + 1, dtype=numpy.int64)
+        numpy.cumsum([x.size for x in sigs], out=bounds[1:])
+        degree = int(splines[0][2])
+        if any(int(sp[2]) != degree for sp in splines):
+            raise ValueError('splines of different degrees in one batch')
+        kb = numpy.zeros(len(sigs) + 1, dtype=numpy.int64)
+        numpy.cumsum([len(sp[0]) for sp in splines], out=kb[1:])
+        t = numpy.concatenate([numpy.asarray(sp[0], dtype=float) for sp in splines])
+        c = numpy.concatenate([numpy.asarray(sp[1], dtype=float)[:len(sp[0])] for sp in splines])
+        up = lambda a: torch.from_numpy(numpy.ascontiguousarray(a)).to(device)
+        out = splev_groups_dev(context, up(numpy.concatenate(sigs)), up(bounds), up(t), up(c), up(kb), degree)
+        host = out.cpu().numpy()
+        for j, r in enumerate(reads):
+            r.tweaked_normalized_signal = host[bounds[j]:bounds[j + 1]].copy()

@@ -178,3 +178,31 @@ def test_renorm_loop_on_device_equals_host_loop(env):
     refit(ev)
     assert np.array_equal(events, ev)
     assert np.allclose(dbatch.signal.cpu().numpy(), sig, rtol=1e-12, atol=1e-13)
+
+
+@pytest.mark.parametrize('degree', [1, 3, 5])
+def test_splev_groups_equals_scipy(env, degree):
+    """FITPACK's splev restated on the device: bit for bit scipy.interpolate.splev (ext=0), smoothing and
+    interpolating splines, few knots (LDS) and many (global memory), samples outside the knots and on them."""
+    from scipy import interpolate
+    from nadavca_amd.device import splev_groups_dev
+    rng = np.random.default_rng(21 + degree)
+    xs, tcks = [], []
+    for npts, smooth in ((40, 1.0), (300, 1.0), (300, 0.05), (700, 0.0), (12, 1.0)):
+        x = np.sort(rng.normal(0, 1.2, npts))
+        x += np.arange(npts) * 1e-9  # strictly increasing for s = 0
+        y = 1.05 * x + 0.1 + 0.3 * np.sin(2 * x) + rng.normal(0, 0.2, npts)
+        tck = interpolate.splrep(x, y, k=degree, s=npts * smooth)
+        tcks.append(tck)
+        xs.append(np.concatenate([rng.normal(0, 1.6, 3000), [-6.0, 6.0, x[0], x[-1]], tck[0]]))
+    assert max(len(t[0]) for t in tcks) > 512 > min(len(t[0]) for t in tcks)
+    off = np.zeros(len(xs) + 1, dtype=np.int64)
+    np.cumsum([len(a) for a in xs], out=off[1:])
+    koff = np.zeros(len(xs) + 1, dtype=np.int64)
+    np.cumsum([len(t[0]) for t in tcks], out=koff[1:])
+    got = splev_groups_dev(env['ctx'], _up(env, np.concatenate(xs), np.float64), _up(env, off, np.int64),
+                           _up(env, np.concatenate([t[0] for t in tcks]), np.float64),
+                           _up(env, np.concatenate([t[1][:len(t[0])] for t in tcks]), np.float64),
+                           _up(env, koff, np.int64), degree).cpu().numpy()
+    for j, (a, tck) in enumerate(zip(xs, tcks)):
+        assert np.array_equal(got[off[j]:off[j + 1]], interpolate.splev(a, tck)), j

@@ -61,3 +61,54 @@ def test_median_rule():
         s = np.sort(a)
         want = s[n // 2] if n % 2 else (s[n // 2 - 1] + s[n // 2]) / 2
         assert want == np.median(a) == statistics.median(a.tolist())
+
+
+# ---- FITPACK splev (de Boor evaluation), as restated by nvk_splev_groups_dev -----------------------------
+def fp_splev(t, c, k, xs):
+    """scipy.interpolate.splev(xs, (t, c, k)) with ext=0: FITPACK's splev.f / fpbspl.f operation for
+    operation (knot interval by position, the stable B-spline recurrence, the dot product in index order)."""
+    t = np.asarray(t, dtype=float)
+    n = len(t)
+    k1 = k + 1
+    nk1 = n - k1
+    out = np.empty(len(xs))
+    for m, x in enumerate(xs):
+        # t[l-1] <= x < t[l] in 1-based FITPACK terms, l clamped to [k1, nk1]
+        l = k1
+        while not (x < t[l] or l == nk1):
+            l += 1
+        h = [0.0] * (k1 + 1)
+        hh = [0.0] * (k1 + 1)
+        h[0] = 1.0
+        for j in range(1, k + 1):
+            for i in range(j):
+                hh[i] = h[i]
+            h[0] = 0.0
+            for i in range(1, j + 1):
+                li = l + i
+                lj = li - j
+                tli, tlj = t[li - 1], t[lj - 1]
+                if tli == tlj:
+                    h[i] = 0.0
+                    continue
+                f = hh[i - 1] / (tli - tlj)
+                h[i - 1] = h[i - 1] + f * (tli - x)
+                h[i] = f * (x - tlj)
+        sp = 0.0
+        ll = l - k1
+        for j in range(k1):
+            sp = sp + c[ll + j] * h[j]
+        out[m] = sp
+    return out
+
+
+def test_splev_restatement_is_scipy():
+    from scipy import interpolate
+    rng = np.random.default_rng(9)
+    for trial in range(6):
+        npts = int(rng.integers(30, 400))
+        x = np.sort(rng.normal(0, 1.2, npts))
+        y = 1.05 * x + 0.1 + 0.3 * np.sin(2 * x) + rng.normal(0, 0.2, npts)
+        tck = interpolate.splrep(x, y, s=npts * (0.2 if trial % 2 else 1.0))
+        xs = np.concatenate([rng.normal(0, 1.5, 500), [-5.0, 5.0, x[0], x[-1]], tck[0]])  # incl. outside, knots
+        assert np.array_equal(fp_splev(tck[0], tck[1], tck[2], xs), interpolate.splev(xs, tck))
