@@ -786,7 +786,7 @@ int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadM
   // Two launches: the LDS rings are sized by the largest skew a launch serves, so the (usual) reads
   // with c <= ALIGN1_C_CAP keep their 16 waves per CU whatever else is in the batch; wide-band reads
   // (long reads, BASELINE config 5) run with larger rings and a longer rescale period.
-  const int C_HARD = 58;  // rescale period 64 must exceed c + mel + 1
+  const int C_HARD = 58;  // rescale period 64 must exceed c + mel
   struct Cls { int lo, hi; int64_t reads; };
   Cls cls[2];
   int ncls = 0;
@@ -801,7 +801,9 @@ int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadM
     // largest value collapses ~70 bits per step, and a period of 16 steps overruns the scale-move cap
     // on 1-2 % of the reads (each such read costs a pass of the exact kernel).
     int rsh = transitions ? 4 : 3;
-    while ((1 << rsh) <= c + mel + 1) rsh++;
+    // (a neighbour value is at most c + mel steps old: a period of c + mel + 1 steps already keeps two
+    // rescale steps out of its way)
+    while ((1 << rsh) <= c + mel) rsh++;
     // history ring: ages 1 .. c+mel are read; the oldest slot is read and then overwritten in the
     // same step (LDS operations of one wave execute in program order)
     const int H = c + mel > 0 ? c + mel : 1;
@@ -817,8 +819,18 @@ int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadM
     const int64_t spill_stride = ((int64_t)max_steps + 2 * PF) * 64;
     const int64_t L_stride = (int64_t)(max_steps >> rsh) + 4;
     const int64_t bp_stride = (int64_t)((max_steps + 31) / 32 + 1) * 64;
-    const int64_t cap = (int64_t)48 << 30;
-    while (slots > 1 && slots * spill_stride * 8 > cap) slots /= 2;
+    // long reads: the spill of one slot is steps * 512 B (170 MB for a 52 k-sample read with bandwidth
+    // 1000); give the resident waves up to 60 % of what is free on the device (288 GB on an MI355X)
+    // beyond what the workspace already holds, and never less than 48 GB worth
+    int64_t cap = (int64_t)48 << 30;
+    {
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        const int64_t avail = (int64_t)((double)(free_b + ctx->ws_bytes[WS_SPILL]) * 0.6);
+        if (avail > cap) cap = avail;
+      }
+    }
+    if (slots * spill_stride * 8 > cap) slots = cap / (spill_stride * 8) > 1 ? cap / (spill_stride * 8) : 1;
     rc = nvk_ws_reserve(ctx, WS_SPILL, (size_t)slots * spill_stride * 8);
     if (rc) return rc;
     rc = nvk_ws_reserve(ctx, WS_STAGE, (size_t)slots * L_stride * 4);
