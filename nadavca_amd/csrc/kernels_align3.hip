@@ -349,6 +349,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
       }
       __syncthreads();
       Scale sc{0, 0, 0};
+      int sh_until = 0;  // (scalar) steps below this one still see values from before the last scale move
       double e = density(ring[i & RM], mean, ac2, mc2, 0, etab);
       int init_live = 1;  // (uniform, a scalar register) the last row is still being swept
       int row0_live = (__builtin_amdgcn_readfirstlane(r) == 0) ? 1 : 0;  // lane 0 is on row 0
@@ -366,6 +367,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
         if (age == 0 && u > 0) {
           sc.L += sc.d_next;
           sc.d_last = sc.d_next;
+          sh_until = (sc.d_next != 0) ? u + c + MEL : 0;
           sc.d_next = 0;
         }
         bool fin = (i < bs);
@@ -412,7 +414,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
         const double pv = hist[hs];
         // scalar shifts that bring a neighbour value from D steps ago to the current scale
         // a rescale lies between the step a neighbour value was produced at and now?  (rare, uniform)
-        const bool sh_any = (age < c + MEL) && (u >= RS) && (sc.d_last != 0);
+        const bool sh_any = (u < sh_until);
         const DensHalf dn = density_begin(xn, mean, ac2, mc2, etab);
         // ---- the cell (r, i): out = P * pred[i + mel] + e(s[i]) * out[i + 1]
 #define ACTIVE_R ((i <= hi) && (i >= bs))
@@ -515,6 +517,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
       }
       __syncthreads();
       Scale sc{0, 0, 0};
+      int sh_until = 0;  // (scalar) steps below this one still see values from before the last scale move
       double e = density(ring[(i - 1) & RM], mean, ac2, mc2, 0, etab);
       int init_live = 1;  // (uniform, scalar registers) row 0 is still being swept
       int top_live = (top < 64) ? 1 : 0;  // the last row has been started
@@ -541,6 +544,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
             if (age == 0 && u > 0) {
               sc.L += sc.d_next;
               sc.d_last = sc.d_next;
+              sh_until = (sc.d_next != 0) ? u + c + MEL : 0;
               sc.d_next = 0;
             }
             bool fin = (i > be);
@@ -585,7 +589,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
             const double xn = ring[i & RM];
             const double2 hv = hist2[hs];
             const int Gin = ghist[hs];
-            const bool sh_any = (age < c + MEL) && (u >= RS) && (sc.d_last != 0);
+            const bool sh_any = (u < sh_until);
             const DensHalf dn = density_begin(xn, mean, ac2, mc2, etab);
             // ---- the cell (r, i): out = P * pred[i - mel] + e(s[i-1]) * out[i - 1]
             // (the band test is only needed on the rare paths below: outside the band the posterior is zero
