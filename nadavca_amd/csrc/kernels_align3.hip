@@ -115,12 +115,13 @@ struct __attribute__((aligned(16))) Lane3 {
                      // - mel).  Everywhere else the lane reads the zero entry of the history ring, which
                      // also keeps its own value at zero outside its span (it starts a row at zero and
                      // leaves it at the span's end), so no other masking is needed.  Empty: 2^30, 0.
-  int32_t mg;        // min event length of the applied step | gap << 4 | adv << 12, where gap is the
-                     // time offset between this row and the row it receives from (the neighbour's value
-                     // is gap + mel steps old) and adv the offset between this row and the lane's
-                     // previous row of the sweep (64 rows back) — RowParam::off, kernels_plan.hip
+  int32_t mg;        // min event length of the applied step | age << 4 | adv << 12: the neighbour's value
+                     // is age = gap + mel >= 1 steps old, gap the time offset between this row and the
+                     // row it receives from (-1 is possible for a row fed by an emitting step); adv (signed)
+                     // the offset between this row and the lane's previous row of the sweep (64 rows
+                     // back) — RowParam::off, kernels_plan.hip
 };
-__device__ __forceinline__ int lane3_pack(int mel, int gap, int adv) { return mel | (gap << 4) | (adv << 12); }
+__device__ __forceinline__ int lane3_pack(int mel, int age, int adv) { return mel | (age << 4) | (adv * 4096); }
 static_assert(sizeof(Lane3) == 48, "Lane3 layout");
 
 struct Align3Args {
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(256) void lane3_kernel(const ReadMeta *metas, const
         const int a = max(f.lo, p.bs + p.mel), z = min(o.be, p.be + p.mel);
         f.pA = (z >= a) ? a : 0x40000000; f.pW = (z >= a) ? z - a : 0;
       }
-      f.mg = lane3_pack(p.mel, o.off - p.off, adv_f);
+      f.mg = lane3_pack(p.mel, o.off - p.off + p.mel, adv_f);
     } else {
       f.mean = 0.0; f.ac = 0.0; f.mc = 0.0; f.mg = lane3_pack(0, 1, 0); f.pA = 0x40000000; f.pW = 0;
     }
@@ -193,11 +194,11 @@ __global__ __launch_bounds__(256) void lane3_kernel(const ReadMeta *metas, const
         const int a = max(o.bs, q.bs - o.mel), z = min(b.end, q.be - o.mel);
         b.pA = (z >= a) ? a : 0x40000000; b.pW = (z >= a) ? z - a : 0;
       }
-      b.mg = lane3_pack(o.mel, q.off - o.off, adv_b);
+      b.mg = lane3_pack(o.mel, q.off - o.off + o.mel, adv_b);
     } else {
       b.pA = 0x40000000; b.pW = 0;
       b.end = o.hi;
-      b.mg = lane3_pack(o.mel, 1, adv_b);
+      b.mg = lane3_pack(o.mel, 1 + o.mel, adv_b);
     }
     fwdl[m.row_off + r] = f;
     revl[m.row_off + r] = b;
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(256) void lane3_kernel(const ReadMeta *metas, const
 #define TAKE_LANE(l)                                                                   \
   do {                                                                                 \
     mean = (l).mean; ac2 = (l).ac; mc2 = (l).mc; melr = (l).mg & 15;                   \
-    D = (((l).mg >> 4) & 255) + melr;                                                  \
+    D = ((l).mg >> 4) & 255;                                                           \
     bs = (l).bs; pA = (l).pA; pW = (l).pW;                                             \
     ra = (int)min((unsigned)(su - D), (unsigned)(su - D + H)) * 64 + nb;               \
     pm = melr ? 1.0 : 0.0; qm = melr ? 0.0 : 1.0;                                      \
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
       int r_old = top;
       int i_old = __builtin_amdgcn_readlane(i, top & 63);  // sample index of the oldest open row (scalar)
       int filled_lo = (i_old / CH + 1) * CH;
-      while (i_old < filled_lo) {
+      while (i_old - 1 < filled_lo) {
         filled_lo -= CH;
         for (int q = lane; q < CH; q += 64) {
           int idx = filled_lo + q;
@@ -395,7 +396,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
           row0_live = (__builtin_amdgcn_readfirstlane(r) == 0) ? 1 : 0;
         }
         if (r_old >= 0) {
-          const int need_min = i_old - 1;
+          const int need_min = i_old - 2;  // (a younger row may be one sample beyond the oldest one)
           while (need_min < filled_lo) {
             filled_lo -= CH;
             __syncthreads();
@@ -421,9 +422,9 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
         double P = emission_product<MEL>(e, e1, e2, e3);
         if (MEL > 0) P = fma(P, pm, qm);  // (1, 0) on emitting rows, (0, 1) on rows without emission: P or 1
         double t1 = P * pv;
-        if (sh_any) {  // the value is D steps old; the last mel of those shifts are in the densities of P
+        if (sh_any) {  // the value missed the moves of its last D steps; P carries those of the last mel
           asm volatile("");
-          t1 = ldexp(t1, (age >= melr && age < D) ? sc.d_last : 0);
+          t1 = ldexp(t1, ((age < D) ? sc.d_last : 0) - ((age < melr) ? sc.d_last : 0));
         }
         double o = fma(e, prev, t1);  // zero outside the lane's span, see Lane3::pA
         if (init_live) {
@@ -508,7 +509,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
       int r_old = 0;
       int i_old = t_min;  // sample index of the oldest open row (scalar): offs[0] = 0
       int filled_hi = ((t_min - MEL - 1) > 0 ? (t_min - MEL - 1) / CH : 0) * CH;
-      while (t_min - 1 >= filled_hi) {
+      while (t_min + 1 >= filled_hi) {
         for (int w = lane; w < CH; w += 64) {
           int idx = filled_hi + w;
           ring[idx & RM] = (idx >= 0 && idx < N) ? sig[idx] : 0.0;
@@ -573,7 +574,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
               top_live = (__builtin_amdgcn_readlane(r, top & 63) == top) ? 1 : 0;
             }
             if (r_old < T) {
-              const int need_max = i_old;
+              const int need_max = i_old + 1;
               while (need_max >= filled_hi) {
                 __syncthreads();
                 for (int w = lane; w < CH; w += 64) {
@@ -601,7 +602,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
             double t1 = P * pv;
             if (sh_any) {  // see the reverse sweep
               asm volatile("");
-              t1 = ldexp(t1, (age >= melr && age < D) ? sc.d_last : 0);
+              t1 = ldexp(t1, ((age < D) ? sc.d_last : 0) - ((age < melr) ? sc.d_last : 0));
             }
             double o = fma(e, prev, t1);
             if (init_live) {

@@ -255,25 +255,54 @@ __global__ __launch_bounds__(PLAN_T) void plan_kernel(DeviceModel dm, BatchArgs 
   // --- per-row time offsets (variable skew, used by kernels_align3.hip) ---------------------------
   // The uniform mapping t = i + c*r pays the worst pair of rows (r - 64, r) of the read on every row.
   // Here cell (r, i) is computed at step t = i + off[r] with the LEAST offsets that satisfy
-  //   gmin <= off[r] - off[r-1] <= c            (neighbour values wait at most c + mel steps in LDS)
+  //   g[r] <= off[r] - off[r-1] <= c            (neighbour values wait at most c + mel steps in LDS)
   //   off[r] - off[r-64] >= hi[r-64] - lo[r] + 1  (a lane is free before its next row starts)
-  // (off[r] = c*r is one solution, so the least one exists and needs no more steps).  With
-  // x[r] = off[r] - gmin*r the first lower bound and the second are a prefix maximum per block of 64
-  // rows, and the upper bound is a suffix maximum of x[r] - (c-gmin)*r; both are iterated to the
-  // fixed point by wave 0 (2-3 rounds on config-shaped reads).  Reads with more rows than the LDS
-  // arrays hold keep the uniform offsets.
+  // (off[r] = c*r is one solution, so the least one exists and needs no more steps).  The lower bound
+  // g[r] is what keeps the neighbour's value at least one step old, age = gap + mel >= 1: 1 for a row
+  // fed without emission (mel 0), 1 - mel for a row fed by an emitting step — with transition rows the
+  // two alternate, so a pair of rows needs no skew at all — and never so low that a row would start or
+  // end before the row above it (the kernel's bookkeeping of the oldest open row relies on that order).
+  // Without transition rows, and for min event lengths above 2, g[r] = max(mel - 1, 1) as before.
+  // With S[r] = g[1] + .. + g[r] and x[r] = off[r] - S[r] the first lower bound and the second are a
+  // prefix maximum per block of 64 rows, and the upper bound is a suffix maximum of off[r] - c*r; both
+  // are iterated to the fixed point by wave 0 (2-4 rounds on config-shaped reads).  Reads with more
+  // rows than the LDS arrays hold keep the uniform offsets.
   constexpr int VT = 2048;
-  __shared__ int sh_k[VT], sh_x[VT];
+  __shared__ int sh_k[VT], sh_x[VT], sh_S[VT];
   __shared__ int sh_var;
   const int gmin = max(mel - 1, 1);
-  const int G1 = c - gmin;
+  const bool neg_gaps = (mode == PLAN_ALIGN_TRANS) && mel <= 2;
   if (tid == 0) sh_var = 0;
   __syncthreads();
-  if (T <= VT && T > 64 && G1 > 0) {
+  if (T <= VT && T > 64 && (neg_gaps || c > gmin)) {
     for (int r = tid; r < T; r += PLAN_T) {
-      sh_k[r] = (r >= 64) ? rp[r - 64].hi - rp[r].lo + 1 - 64 * gmin : 0;
+      int g = 0;
+      if (r > 0) {
+        g = gmin;
+        if (neg_gaps) g = max(1 - rp[r - 1].mel, max(rp[r - 1].lo - rp[r].lo, rp[r - 1].hi - rp[r].hi));
+        g = min(g, c);
+      }
+      sh_S[r] = g;
       sh_x[r] = 0;
     }
+    __syncthreads();
+    if (tid < 64) {  // S: inclusive prefix sum, block by block
+      int carry = 0;
+      for (int b0 = 0; b0 < T; b0 += 64) {
+        const int r = b0 + lane;
+        int v = r < T ? sh_S[r] : 0;
+        for (int d = 1; d < 64; d <<= 1) {
+          const int o = __shfl_up(v, d, 64);
+          if (lane >= d) v += o;
+        }
+        v += carry;
+        if (r < T) sh_S[r] = v;
+        carry = __shfl(v, 63, 64);
+      }
+    }
+    __syncthreads();
+    for (int r = tid; r < T; r += PLAN_T)
+      sh_k[r] = (r >= 64) ? rp[r - 64].hi - rp[r].lo + 1 - (sh_S[r] - sh_S[r - 64]) : 0;
     __syncthreads();
     if (tid < 64) {
       const int NEG = -0x20000000;
@@ -303,14 +332,15 @@ __global__ __launch_bounds__(PLAN_T) void plan_kernel(DeviceModel dm, BatchArgs 
         for (int b0 = ((T - 1) / 64) * 64; b0 >= 0; b0 -= 64) {  // gap limit, descending
           const int r = b0 + lane;
           const int cur = r < T ? sh_x[r] : 0;
-          int z = r < T ? cur - G1 * r : NEG;
+          const int U = r < T ? c * r - sh_S[r] : 0;  // off[r] - c*r = x[r] - U[r]
+          int z = r < T ? cur - U : NEG;
           for (int d = 1; d < 64; d <<= 1) {
             const int o = __shfl_down(z, d, 64);
             if (lane + d < 64) z = max(z, o);
           }
           z = max(z, carryz);
           if (r < T) {
-            const int nx = z + G1 * r;
+            const int nx = z + U;
             changed |= (nx != cur);
             sh_x[r] = nx;
           }
@@ -324,8 +354,8 @@ __global__ __launch_bounds__(PLAN_T) void plan_kernel(DeviceModel dm, BatchArgs 
   }
   const bool var_ok = (sh_var != 0);
   const int x0 = var_ok ? sh_x[0] : 0;
-  for (int r = tid; r < T; r += PLAN_T) rp[r].off = var_ok ? sh_x[r] - x0 + gmin * r : c * r;
-  const int off_top = var_ok ? sh_x[T - 1] - x0 + gmin * (T - 1) : c * (T - 1);
+  for (int r = tid; r < T; r += PLAN_T) rp[r].off = var_ok ? sh_x[r] - x0 + sh_S[r] : c * r;
+  const int off_top = var_ok ? sh_x[T - 1] - x0 + sh_S[T - 1] : c * (T - 1);
 
   if (tid == 0) {
     int t_min = rp[0].lo;
