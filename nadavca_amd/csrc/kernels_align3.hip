@@ -36,9 +36,11 @@
 // second launch with larger rings and a longer rescale period.
 //
 // Time mapping: cell (r, i) is computed at step t = i + off[r] with the planner's per-row offsets
-// (RowParam::off, kernels_plan.hip) instead of one skew per read; a lane record carries the row's gap
-// to the row it receives from (the neighbour's value is gap + mel steps old) and its advance over the
-// lane's previous row.
+// (RowParam::off, kernels_plan.hip) instead of one skew per read; a lane record carries the age of the
+// neighbour's value (gap to the row it receives from + mel, at least 1; the gap itself may be -1 for a
+// row fed by an emitting step) and the row's advance over the lane's previous row.  A value that is D
+// steps old missed the scale moves of its last D steps, the emission product carries those of its
+// last mel steps: the correction applied to their product is ([age < D] - [age < mel]) * last move.
 //
 // What the step does NOT do any more (each was measured): no masks on loaded or
 // computed values — a lane reads a permanent zero entry of the history ring wherever it is outside its
