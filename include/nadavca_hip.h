@@ -54,8 +54,11 @@ enum {
 enum {
   NVK_READ_OK = 0,
   NVK_READ_NO_PATH = 1,       /* reference: refine_alignment returns [] (dtw.cpp:211-213) */
-  NVK_READ_BAD_INPUT = -1,    /* empty reference/signal, anchor outside the reference */
-  NVK_READ_BAD_BAND = -2      /* band_end < band_start for some row (reference: UB / length_error) */
+  NVK_READ_BAD_INPUT = -1,    /* empty reference/signal, anchor outside the reference, a base code outside
+                                 0..alphabet-1 in the reference or a context, offsets beyond total_* */
+  NVK_READ_BAD_BAND = -2,     /* band_end < band_start for some row (reference: UB / length_error) */
+  NVK_READ_TOO_WIDE = -3      /* the read's band is wider than the compiled kernels' on-chip rings hold
+                                 (limits); the other reads of the batch are unaffected */
 };
 
 /* kernel ids for nvk_timing_read */
@@ -92,6 +95,25 @@ int nvk_last_batch_stats(nvk_ctx *ctx, int64_t *band_cells, int64_t *wave_steps,
 /* reads of the last nvk_refine_alignment_batch[_dev] call that left the fast kernel's number range
  * and were recomputed by the exact kernel (results are the same either way; this is a cost figure) */
 int nvk_last_retry_count(nvk_ctx *ctx, int64_t *n_reads);
+/* PARITY CONTRACT of refine_alignment.  The reference decides every step of its path search with a strict
+ * `>` between natural-log doubles (/root/reference/nadavca/dtw/node.cpp:52,72,82).  This engine computes
+ * the same scores as scaled linear numbers (2^-53 relative precision) and takes `a > b` only if a exceeds
+ * b by more than one ulp of the reference's log value (relative margin |exponent| * 2^-52), so that a
+ * plateau the reference sees as flat — the boundary between two adjacent bases with the same k-mer level —
+ * resolves to the first maximum as it does there.  Results are therefore IDENTICAL to the reference's
+ * except possibly in reads where some comparison fell INSIDE that margin (there the reference's own
+ * choice is decided by its rounding noise).  Such reads are counted and flagged:
+ *   nvk_last_tie_count   number of reads of the last nvk_refine_alignment_batch[_dev] call in which at
+ *                        least one path comparison was closer than the margin
+ *   nvk_last_tie_flags   per read, nonzero = such a comparison occurred; out_flags i32[n_reads] (host),
+ *                        n_reads must be that call's n_reads
+ * A read with flag 0 has the reference's events exactly (tests/test_gpu_parity_full.py). */
+int nvk_last_tie_count(nvk_ctx *ctx, int64_t *n_reads);
+int nvk_last_tie_flags(nvk_ctx *ctx, int64_t n_reads, int32_t *out_flags);
+/* Cap, in bytes, on the device memory the sweep kernels take for their per-wave spill (the suffix rows of
+ * the reads in flight: 512 B per wavefront step and resident wave).  0 (default): up to 60 % of the memory
+ * that is free at the call.  Fewer waves run concurrently when the cap binds; results do not change. */
+int nvk_ctx_set_workspace_limit(nvk_ctx *ctx, int64_t bytes);
 
 /* replaces dtw.KmerModel(k, central_position, alphabet_size, mean, sigma)
  * (dtwmodule.cpp:12-13, kmer_model.cpp:6-14).  mean/sigma: host f64[n], n = alphabet^k */

@@ -21,6 +21,7 @@ READ_OK = 0
 READ_NO_PATH = 1
 READ_BAD_INPUT = -1
 READ_BAD_BAND = -2
+READ_TOO_WIDE = -3
 
 K_PLAN, K_ALIGN, K_ELL_SWEEP, K_ELL_HYP, K_EXPECTED, K_CONSENSUS, K_POSTERIOR, K_RENORM = range(8)
 KERNEL_NAMES = ['plan', 'align', 'ell_sweep', 'ell_hyp', 'expected', 'consensus', 'posterior', 'renorm']
@@ -44,6 +45,9 @@ SIGNATURES = {
     'nvk_timing_read': (_int, [_vp, _int, C.POINTER(_dbl), C.POINTER(_i64)]),
     'nvk_last_batch_stats': (_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     'nvk_last_retry_count': (_int, [_vp, C.POINTER(_i64)]),
+    'nvk_last_tie_count': (_int, [_vp, C.POINTER(_i64)]),
+    'nvk_last_tie_flags': (_int, [_vp, _i64, _vp]),
+    'nvk_ctx_set_workspace_limit': (_int, [_vp, _i64]),
     'nvk_model_create': (_int, [_vp, _int, _int, _int, _vp, _vp, _i64, C.POINTER(_vp)]),
     'nvk_model_destroy': (None, [_vp]),
     'nvk_model_info': (_int, [_vp, C.POINTER(_int), C.POINTER(_int), C.POINTER(_int)]),
@@ -153,7 +157,21 @@ class Context:
               'nvk_last_batch_stats')
         d = _i64()
         check(self._lib.nvk_last_retry_count(self.handle, C.byref(d)), 'nvk_last_retry_count')
-        return dict(band_cells=a.value, wave_steps=b.value, spill_bytes=c.value, reads_redone_exact=d.value)
+        e = _i64()
+        check(self._lib.nvk_last_tie_count(self.handle, C.byref(e)), 'nvk_last_tie_count')
+        return dict(band_cells=a.value, wave_steps=b.value, spill_bytes=c.value, reads_redone_exact=d.value,
+                    reads_tie_ambiguous=e.value)
+
+    def last_tie_flags(self, n_reads):
+        """Per read of the last refine_alignment batch: nonzero where a path comparison fell inside the
+        tolerance band (include/nadavca_hip.h, parity contract)."""
+        import numpy as np
+        out = np.zeros(int(n_reads), dtype=np.int32)
+        check(self._lib.nvk_last_tie_flags(self.handle, int(n_reads), _vp(out.ctypes.data)), 'nvk_last_tie_flags')
+        return out
+
+    def set_workspace_limit(self, nbytes):
+        check(self._lib.nvk_ctx_set_workspace_limit(self.handle, int(nbytes)), 'nvk_ctx_set_workspace_limit')
 
     def close(self):
         if getattr(self, 'handle', None):

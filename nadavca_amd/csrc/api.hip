@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <new>
 #include <vector>
 
 #include "nvk_internal.h"
@@ -52,6 +53,20 @@ int nvk_ws_reserve(nvk_ctx *ctx, int which, size_t bytes) {
   return NVK_OK;
 }
 
+int64_t nvk_spill_cap(nvk_ctx *ctx, int which_ws) {
+  if (ctx->ws_limit > 0) return ctx->ws_limit;  // nvk_ctx_set_workspace_limit
+  // default: up to 60 % of what is free on the device beyond what this workspace already holds (long
+  // reads: one resident wave spills steps * 512 B, 170 MB for a 52 k-sample read with bandwidth 1000),
+  // and never less than 48 GB worth
+  int64_t cap = (int64_t)48 << 30;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+    const int64_t avail = (int64_t)((double)(free_b + ctx->ws_bytes[which_ws]) * 0.6);
+    if (avail > cap) cap = avail;
+  }
+  return cap;
+}
+
 TimerScope::TimerScope(nvk_ctx *c, int kid) : ctx(c), id(kid) {
   if (ctx->timing_on) (void)hipEventRecord(ctx->ev0, ctx->stream);
 }
@@ -83,7 +98,11 @@ extern "C" int nvk_ctx_create(int device, nvk_ctx **out) {
     return NVK_ERR_INVALID;
   }
   NVK_HIP(hipSetDevice(device));
-  nvk_ctx *c = new nvk_ctx();
+  nvk_ctx *c = new (std::nothrow) nvk_ctx();
+  if (!c) {
+    nvk_set_error("nvk_ctx_create: out of host memory");
+    return NVK_ERR_NOMEM;
+  }
   memset(c, 0, sizeof *c);
   c->device = device;
   hipDeviceProp_t prop;
@@ -93,11 +112,12 @@ extern "C" int nvk_ctx_create(int device, nvk_ctx **out) {
     return NVK_ERR_HIP;
   }
   c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  // (nvk_ctx_destroy skips what was never created: every handle starts out null)
   if (hipStreamCreate(&c->stream) != hipSuccess || hipStreamCreate(&c->stream2) != hipSuccess ||
       hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
-    delete c;
+    nvk_ctx_destroy(c);
     nvk_set_error("stream/event creation failed");
     return NVK_ERR_HIP;
   }
@@ -108,16 +128,16 @@ extern "C" int nvk_ctx_create(int device, nvk_ctx **out) {
 extern "C" void nvk_ctx_destroy(nvk_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
-  (void)hipStreamSynchronize(ctx->stream);
-  (void)hipStreamSynchronize(ctx->stream2);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
   for (int i = 0; i < WS_COUNT; i++)
     if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
-  (void)hipEventDestroy(ctx->ev0);
-  (void)hipEventDestroy(ctx->ev1);
-  (void)hipEventDestroy(ctx->ev_fork);
-  (void)hipEventDestroy(ctx->ev_join);
-  (void)hipStreamDestroy(ctx->stream2);
-  (void)hipStreamDestroy(ctx->stream);
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+  if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
 
@@ -172,6 +192,33 @@ extern "C" int nvk_last_retry_count(nvk_ctx *ctx, int64_t *n_reads) {
   return NVK_OK;
 }
 
+extern "C" int nvk_last_tie_count(nvk_ctx *ctx, int64_t *n_reads) {
+  if (!ctx || !n_reads) return NVK_ERR_INVALID;
+  *n_reads = ctx->last_ties;
+  return NVK_OK;
+}
+
+extern "C" int nvk_last_tie_flags(nvk_ctx *ctx, int64_t n_reads, int32_t *out_flags) {
+  if (!ctx || !out_flags || n_reads < 0) return NVK_ERR_INVALID;
+  if (n_reads != ctx->ties_n) {
+    nvk_set_error("nvk_last_tie_flags: the last refine_alignment batch had %lld reads, not %lld",
+                  (long long)ctx->ties_n, (long long)n_reads);
+    return NVK_ERR_INVALID;
+  }
+  if (n_reads == 0) return NVK_OK;
+  NVK_HIP(hipSetDevice(ctx->device));
+  NVK_HIP(hipMemcpyAsync(out_flags, ctx->ws[WS_TIES], (size_t)n_reads * sizeof(int32_t), hipMemcpyDeviceToHost,
+                         ctx->stream));
+  NVK_HIP(hipStreamSynchronize(ctx->stream));
+  return NVK_OK;
+}
+
+extern "C" int nvk_ctx_set_workspace_limit(nvk_ctx *ctx, int64_t bytes) {
+  if (!ctx || bytes < 0) return NVK_ERR_INVALID;
+  ctx->ws_limit = bytes;
+  return NVK_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // model
 // ---------------------------------------------------------------------------------------------
@@ -198,13 +245,24 @@ extern "C" int nvk_model_create(nvk_ctx *ctx, int k, int central_position, int a
   }
   NVK_HIP(hipSetDevice(ctx->device));
   // additive / multiplicative constants exactly as kmer_model.cpp:9-12 spells them
-  std::vector<double> ac((size_t)n), mc((size_t)n);
+  std::vector<double> ac, mc;
+  try {
+    ac.resize((size_t)n);
+    mc.resize((size_t)n);
+  } catch (const std::bad_alloc &) {
+    nvk_set_error("nvk_model_create: out of host memory");
+    return NVK_ERR_NOMEM;
+  }
   for (int64_t i = 0; i < n; i++) {
     double s = sigma[i];
     ac[(size_t)i] = log(1 / sqrt(2 * M_PI * s * s));
     mc[(size_t)i] = 1 / (2 * s * s);
   }
-  nvk_model *m = new nvk_model();
+  nvk_model *m = new (std::nothrow) nvk_model();
+  if (!m) {
+    nvk_set_error("nvk_model_create: out of host memory");
+    return NVK_ERR_NOMEM;
+  }
   memset(m, 0, sizeof *m);
   m->ctx = ctx;
   size_t bytes = (size_t)n * sizeof(double);
@@ -215,9 +273,13 @@ extern "C" int nvk_model_create(nvk_ctx *ctx, int k, int central_position, int a
     nvk_model_destroy(m);
     return NVK_ERR_NOMEM;
   }
-  NVK_HIP(hipMemcpy(m->d_mean, mean, bytes, hipMemcpyHostToDevice));
-  NVK_HIP(hipMemcpy(m->d_ac, ac.data(), bytes, hipMemcpyHostToDevice));
-  NVK_HIP(hipMemcpy(m->d_mc, mc.data(), bytes, hipMemcpyHostToDevice));
+  if (hipMemcpy(m->d_mean, mean, bytes, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(m->d_ac, ac.data(), bytes, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(m->d_mc, mc.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) {
+    nvk_set_error("nvk_model_create: copying the table to the device failed");
+    nvk_model_destroy(m);
+    return NVK_ERR_HIP;
+  }
   m->dm.k = k;
   m->dm.central = central_position;
   m->dm.alphabet = alphabet_size;
@@ -446,6 +508,11 @@ extern "C" int nvk_refine_alignment_batch_dev(
     nvk_set_error("min_event_length %d outside the compiled range 0..4", min_event_length);
     return NVK_ERR_UNSUPPORTED;
   }
+  if (total_signal < 0 || total_ref < 0 || total_anchors < 0 || !sig_off || !ref_off || !cb_off || !ca_off ||
+      !anc_off || !out_status) {
+    nvk_set_error("negative total or NULL offset/status pointer");
+    return NVK_ERR_INVALID;
+  }
   nvk_ctx *ctx = model->ctx;
   NVK_HIP(hipSetDevice(ctx->device));
   if (n_reads == 0) return NVK_OK;
@@ -468,74 +535,50 @@ extern "C" int nvk_refine_alignment_batch_dev(
   a.bandwidth = bandwidth;
   a.mel = min_event_length;
   PlanTotals tot;
-  // three implementations of the same operator with identical results (all parity-tested):
+  // two implementations of the same operator with identical results (both parity-tested):
   //   default                  kernels_align3.hip (plain doubles, wave-uniform scale) with
   //                            kernels_align.hip as the exact fallback for reads it flags
   //   NADAVCA_ALIGN_KERNEL=1   kernels_align.hip only (mantissa+exponent per value)
-  //   NADAVCA_ALIGN_KERNEL=2   kernels_align4.hip (fused lanes, two reads per wave, plain doubles
-  //                            under a per-half scale; same exact fallback)
   const char *force = getenv("NADAVCA_ALIGN_KERNEL");
   ctx->last_retries = 0;
-  bool use_v1 = !(force && force[0] == '2');
-  if (!use_v1) {
-    const int64_t n = n_reads, nrow = total_ref + n;
-    if ((rc = nvk_ws_reserve(ctx, WS_META, (size_t)(n + 1) * sizeof(ReadMeta) + 64))) return rc;
-    if ((rc = nvk_ws_reserve(ctx, WS_ROWS, (size_t)(nrow + 1) * sizeof(AlignLane)))) return rc;
-    if ((rc = nvk_ws_reserve(ctx, WS_ROWS2, (size_t)(nrow + 1) * sizeof(AlignLane)))) return rc;
-    if ((rc = nvk_ws_reserve(ctx, WS_BANDTMP, (size_t)(2 * nrow + 2) * 8))) return rc;
-    if ((rc = nvk_ws_reserve(ctx, WS_MISC, 256))) return rc;
-    Align2Plan pl;
-    pl.metas = (ReadMeta *)ctx->ws[WS_META];
-    pl.fwd = (AlignLane *)ctx->ws[WS_ROWS];
-    pl.rev = (AlignLane *)ctx->ws[WS_ROWS2];
-    PlanTotals *d_tot = (PlanTotals *)((char *)ctx->ws[WS_MISC] + 64);
-    rc = launch_plan_align2(ctx, model->dm, a, model_transitions ? 1 : 0, ALIGN2_C_CAP, pl,
-                            (unsigned long long *)ctx->ws[WS_BANDTMP], d_tot);
+  ctx->last_ties = 0;
+  rc = plan_batch(model, a, model_transitions ? PLAN_ALIGN_TRANS : PLAN_ALIGN_PLAIN, 0, tot);
+  if (rc) return rc;
+  if ((rc = nvk_ws_reserve(ctx, WS_TIES, (size_t)(n_reads + 1) * sizeof(int32_t)))) return rc;
+  NVK_HIP(hipMemsetAsync(ctx->ws[WS_TIES], 0, (size_t)(n_reads + 1) * sizeof(int32_t), ctx->stream));
+  ctx->ties_n = n_reads;
+  const ReadMeta *metas = (const ReadMeta *)ctx->ws[WS_META];
+  const RowParam *rows = (const RowParam *)ctx->ws[WS_ROWS];
+  bool exact_all = force && force[0] == '1';
+  if (!exact_all) {
+    // fast path: plain doubles under a wave-uniform scale (bit-identical while in range);
+    // reads it cannot serve come back flagged and are redone by the exact kernel below
+    int n_retry = 0;
+    rc = launch_align3(ctx, a, model_transitions ? 1 : 0, metas, rows, tot, out_events, out_status,
+                       &n_retry);
+    ctx->last_retries = n_retry;
     if (rc) return rc;
-    NVK_HIP(hipMemcpyAsync(&tot, d_tot, sizeof(PlanTotals), hipMemcpyDeviceToHost, ctx->stream));
-    NVK_HIP(hipStreamSynchronize(ctx->stream));
-    ctx->last_cells = (int64_t)tot.cells;
-    ctx->last_steps = (int64_t)tot.steps;
-    {
-      int n_retry = 0;
-      rc = launch_align4(ctx, a, model_transitions ? 1 : 0, pl, tot, out_events, out_status, &n_retry);
-      ctx->last_retries = n_retry;
-      if (rc == NVK_OK && n_retry > 0) {  // flagged reads: exact kernel (own planner, same inputs)
-        rc = plan_batch(model, a, model_transitions ? PLAN_ALIGN_TRANS : PLAN_ALIGN_PLAIN, 0, tot);
-        if (rc) return rc;
-        rc = launch_align_retry(ctx, a, model_transitions ? 1 : 0, (const ReadMeta *)ctx->ws[WS_META],
-                                (const RowParam *)ctx->ws[WS_ROWS], tot, out_events, out_status);
-        if (rc) return rc;
-      }
-    }
-    if (rc == NVK_ERR_UNSUPPORTED) use_v1 = true;  // band too wide for the paired layout
-    else if (rc) return rc;
-  }
-  if (use_v1) {
-    rc = plan_batch(model, a, model_transitions ? PLAN_ALIGN_TRANS : PLAN_ALIGN_PLAIN, 0, tot);
-    if (rc) return rc;
-    const ReadMeta *metas = (const ReadMeta *)ctx->ws[WS_META];
-    const RowParam *rows = (const RowParam *)ctx->ws[WS_ROWS];
-    bool exact_all = force && force[0] == '1';
-    if (!exact_all) {
-      // fast path: plain doubles under a wave-uniform scale (bit-identical while in range);
-      // reads it cannot serve come back flagged and are redone by the exact kernel below
-      int n_retry = 0;
-      rc = launch_align3(ctx, a, model_transitions ? 1 : 0, metas, rows, tot, out_events, out_status,
-                         &n_retry);
-      ctx->last_retries = n_retry;
-      if (rc == NVK_ERR_UNSUPPORTED) exact_all = true;
-      else if (rc) return rc;
-      else if (n_retry > 0 && !getenv("NADAVCA_ALIGN3_NORETRY")) {  // (debug switch: leave flags visible)
-        rc = launch_align_retry(ctx, a, model_transitions ? 1 : 0, metas, rows, tot, out_events,
-                                out_status);
-        if (rc) return rc;
-      }
-    }
-    if (exact_all) {
-      rc = launch_align(ctx, a, model_transitions ? 1 : 0, metas, rows, tot, out_events, out_status);
+    bool redo = n_retry > 0;
+#ifdef NVK_DEBUG_SWITCHES
+    if (getenv("NADAVCA_ALIGN3_NORETRY")) redo = false;  // debug builds only: leave the flags visible
+#endif
+    if (redo) {
+      rc = launch_align_retry(ctx, a, model_transitions ? 1 : 0, metas, rows, tot, out_events,
+                              out_status);
       if (rc) return rc;
     }
+  } else {
+    rc = launch_align(ctx, a, model_transitions ? 1 : 0, metas, rows, tot, out_events, out_status);
+    if (rc) return rc;
+  }
+  {  // reads in which a path decision fell inside the comparison tolerance (include/nadavca_hip.h)
+    int32_t *d_ties = (int32_t *)ctx->ws[WS_TIES];
+    int32_t n_ties = 0;
+    rc = launch_count_flags(ctx, d_ties, n_reads, d_ties + n_reads);
+    if (rc) return rc;
+    NVK_HIP(hipMemcpyAsync(&n_ties, d_ties + n_reads, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    NVK_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->last_ties = n_ties;
   }
   NVK_HIP(hipStreamSynchronize(ctx->stream));
   return NVK_OK;
@@ -590,6 +633,11 @@ extern "C" int nvk_estimate_log_likelihoods_batch_dev(
   if (min_event_length > 4) {
     nvk_set_error("min_event_length %d outside the compiled range 0..4", min_event_length);
     return NVK_ERR_UNSUPPORTED;
+  }
+  if (total_signal < 0 || total_ref < 0 || total_anchors < 0 || !sig_off || !ref_off || !cb_off || !ca_off ||
+      !anc_off || !out_status) {
+    nvk_set_error("negative total or NULL offset/status pointer");
+    return NVK_ERR_INVALID;
   }
   nvk_ctx *ctx = model->ctx;
   NVK_HIP(hipSetDevice(ctx->device));

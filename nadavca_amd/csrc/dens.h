@@ -49,7 +49,11 @@ __device__ __forceinline__ DensHalf density_begin(double x, double mean, double 
   const double kk = rint(y);
   const double gq = y - kk;
   h.ki = (int)kk;
+#if defined(NVK_ABL) && NVK_ABL == 1
+  h.tj = 1.0;  // ablation: no table read
+#else
   h.tj = etab[h.ki & (ETN - 1)];
+#endif
   double p = fma_vvv(gq, 0x1.5d87fe78a6731p-45, 0x1.3b2ab6fba4e77p-35);
   p = fma_vvv(p, gq, 0x1.c6b08d704a0c0p-26);
   p = fma_vvv(p, gq, 0x1.ebfbdff82c58fp-17);
@@ -63,8 +67,26 @@ __device__ __forceinline__ double density_end(const DensHalf &h, int dshift) {
 
 
 // the table itself: 1 KB of LDS per block, filled once per kernel
+__device__ __forceinline__ double table_entry(int q) { return exp2((double)q * (1.0 / ETN)); }
 __device__ __forceinline__ void fill_table(double *etab, int lane, int nthreads) {
-  for (int q = lane; q < ETN; q += nthreads) etab[q] = exp2((double)q * (1.0 / ETN));
+  for (int q = lane; q < ETN; q += nthreads) etab[q] = table_entry(q);
+}
+
+// What density() returns for a row whose density does not depend on the sample (mc == 0, `ac` already
+// scaled by scale_consts), without the LDS table: the same operations on the same table entry, so the
+// value is the one the kernels compute.  Used to put a transition row's constant into its lane record.
+__device__ __forceinline__ double constant_density(double ac) {
+  const double y = ac;
+  const double kk = rint(y);
+  const double gq = y - kk;
+  const int ki = (int)kk;
+  const double tj = table_entry(ki & (ETN - 1));
+  double p = fma_vvv(gq, 0x1.5d87fe78a6731p-45, 0x1.3b2ab6fba4e77p-35);
+  p = fma_vvv(p, gq, 0x1.c6b08d704a0c0p-26);
+  p = fma_vvv(p, gq, 0x1.ebfbdff82c58fp-17);
+  p = fma_vvv(p, gq, 0x1.62e42fefa39efp-8);
+  p = fma(p, gq, 1.0);
+  return ldexp(tj * p, ki >> 7);
 }
 
 // row constants as density() wants them: the reference's ac/mc (kmer_model.cpp:9-12) times

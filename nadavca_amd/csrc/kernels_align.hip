@@ -60,6 +60,8 @@ struct AlignArgs {
   int transitions;
   int wide, c_cap;  // class served by this launch: skew <= c_cap (wide = 0) or above (wide = 1)
   int only_retry;   // serve only reads flagged NVK_READ_RETRY_INTERNAL by the scaled-double kernel
+  int c_max;        // largest skew this launch's LDS rings hold: wider reads get NVK_READ_TOO_WIDE
+  int32_t *ties;    // per read: a path comparison fell inside the tolerance band (nvk_last_tie_flags)
   int32_t *out_events;
   int32_t *out_status;
 };
@@ -120,6 +122,10 @@ __global__ __launch_bounds__(64) void align_kernel(AlignArgs g) {
     }
     if ((m.c > g.c_cap) != (g.wide != 0)) continue;  // served by the other launch
     if (g.only_retry && g.out_status[rd] != NVK_READ_RETRY_INTERNAL) continue;
+    if (m.c > g.c_max) {  // the band does not fit one wave's rings: this read only
+      if (lane == 0) g.out_status[rd] = NVK_READ_TOO_WIDE;
+      continue;
+    }
     const int T = __builtin_amdgcn_readfirstlane(m.T);
     const int N = __builtin_amdgcn_readfirstlane(m.N);
     const int c = __builtin_amdgcn_readfirstlane(m.c);
@@ -248,6 +254,7 @@ __global__ __launch_bounds__(64) void align_kernel(AlignArgs g) {
     // ================= forward sweep: prefix rows, posterior, path DP, update bits =================
     X fbest = xm::zero();
     int fidx = -1;
+    bool amb = false;  // a comparison inside the tolerance band (xm::near_tol)
     {
       int r = lane;
       int loaded_hi = 0;
@@ -359,12 +366,14 @@ __global__ __launch_bounds__(64) void align_kernel(AlignArgs g) {
             // posterior * running max of the previous row (node.cpp:52-91): strict '>' keeps
             // the first maximum
             const bool upd = active && xm::gt_tol(dv, best);
+            amb |= active && xm::near_tol(dv, best);
             best = xm::sel(upd, dv, best);
             bits |= upd ? (1u << (u & 31)) : 0u;
             X post{o.m * cur_m[q], o.e + cur_e[q] - K};
             X dpv = is_init ? post : xm::mul(best, post);
             dpv = xm::norm(dpv);
             dpv = xm::sel(in_band, dpv, xm::zero());
+            amb |= (r == top) && xm::near_tol(dpv, fbest);
             if (r == top && xm::gt_tol(dpv, fbest)) {
               fbest = dpv;
               fidx = i;
@@ -402,6 +411,7 @@ __global__ __launch_bounds__(64) void align_kernel(AlignArgs g) {
       if (lane == 0) g.out_status[rd] = NVK_READ_NO_PATH;
       continue;
     }
+    if (__any(amb) && lane == 0) g.ties[rd] = 1;
     if (lane == 0) {
       int32_t *ev = g.out_events + 2 * m.ref_off;
       int st = NVK_READ_OK;
@@ -472,15 +482,19 @@ static int launch_align_impl(nvk_ctx *ctx, const BatchArgs &a, int transitions, 
     const int64_t n_class = wide ? tot.n_wide : a.n_reads - tot.n_wide;
     if (n_class <= 0) continue;
     hipStream_t st = wide ? ctx->stream2 : ctx->stream;
-    const int c = wide ? max_c : (max_c < ALIGN1_C_CAP ? max_c : ALIGN1_C_CAP);
-    const int H = c + mel + 1;  // the slot read is c+mel steps old; one more so it is not yet overwritten
-    int SR = 256;
-    while (SR < 64 * c + CH) SR <<= 1;
-    size_t lds = (size_t)SR * 8 + (size_t)TABN * sizeof(RowParam) + 2 * (size_t)H * 64 * 12 + 16;
-    if (lds > 160 * 1024) {
-      nvk_set_error("band too wide for one wave per read: skew %d needs %zu bytes of LDS", c, lds);
-      return NVK_ERR_UNSUPPORTED;
-    }
+    // the largest skew whose rings fit 160 KB of LDS; reads beyond it get NVK_READ_TOO_WIDE (kernel)
+    auto lds_for = [&](int cc, int *pH, int *pSR) {
+      const int H = cc + mel + 1;  // the slot read is c+mel steps old; one more so it is not yet overwritten
+      int SR = 256;
+      while (SR < 64 * cc + CH) SR <<= 1;
+      if (pH) *pH = H;
+      if (pSR) *pSR = SR;
+      return (size_t)SR * 8 + (size_t)TABN * sizeof(RowParam) + 2 * (size_t)H * 64 * 12 + 16;
+    };
+    int c = wide ? max_c : (max_c < ALIGN1_C_CAP ? max_c : ALIGN1_C_CAP);
+    while (c > 1 && lds_for(c, nullptr, nullptr) > 160 * 1024) c--;
+    int H, SR;
+    const size_t lds = lds_for(c, &H, &SR);
     // waves resident per CU are bounded by LDS; more than 4 per SIMD buys nothing here
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu > 16) per_cu = 16;
@@ -490,7 +504,7 @@ static int launch_align_impl(nvk_ctx *ctx, const BatchArgs &a, int transitions, 
     // per-slot workspace, padded by 2*PF steps so that prefetches past the end stay in bounds
     const int64_t spill_stride = ((int64_t)max_steps + 2 * PF) * 64;
     const int64_t bp_stride = (int64_t)((max_steps + 31) / 32 + 1) * 64;
-    const int64_t cap = (int64_t)48 << 30;
+    const int64_t cap = nvk_spill_cap(ctx, wide ? WS_SPILL_B : WS_SPILL);
     while (slots > 1 && slots * spill_stride * 12 > cap) slots /= 2;
     const int wsm = wide ? WS_SPILL_B : WS_SPILL, wse = wide ? WS_STAGE_B : WS_STAGE,
               wsb = wide ? WS_BP_B : WS_BP;
@@ -522,6 +536,8 @@ static int launch_align_impl(nvk_ctx *ctx, const BatchArgs &a, int transitions, 
     g.wide = wide;
     g.c_cap = ALIGN1_C_CAP;
     g.only_retry = only_retry;
+    g.c_max = c;
+    g.ties = (int32_t *)ctx->ws[WS_TIES];
     g.out_events = out_events;
     g.out_status = out_status;
 

@@ -55,9 +55,22 @@
 // update bits shifted in with v_addc (inline assembly blocks the scheduler: +1 %).
 #include <math.h>
 
+#include <new>
+#include <vector>
+
 #include "nvk_internal.h"
 #include "xmath.h"
 #include "dens.h"
+
+#ifndef NVK_ABL
+#define NVK_ABL 0  // ablation experiments (timing only, results are wrong): see tools/README.md
+#endif
+#ifndef NVK_NO_TIEFLAG
+#define NVK_NO_TIEFLAG 0  // (development switch: what the tie flag costs)
+#endif
+#ifndef NVK_PAIR_DEBUG
+#define NVK_PAIR_DEBUG 0  // 1: paired arithmetic, but every lane evaluates its own density at every step
+#endif
 
 namespace {
 
@@ -86,12 +99,19 @@ constexpr int TARGET = 250; // exponent the largest live value is moved to
 // The spill is addressed through a buffer resource: address = resource base (scalar) + scalar byte
 // offset of the step + per-lane byte offset (a constant vector register), so neither the store of the
 // reverse sweep nor the prefetch of the forward sweep needs vector address arithmetic.
-typedef int v2i_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void spill_store(__amdgpu_buffer_rsrc_t rs, int lane8, int step, double v) {
-  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i_t, v), rs, lane8, step * 512, 0);
+// Two consecutive steps travel together: 16 bytes per lane and access (8-byte accesses reach little more
+// than half of the HBM rate 16-byte ones do, MI355X_MICROARCH.md; measured here: the spill traffic in
+// 8-byte pieces cost a quarter of the kernel's time).  Pair p holds steps 2p and 2p+1 of the FORWARD
+// order, [pair][lane][2]; the planner makes the step count even so that the reverse sweep, which runs the
+// steps downwards, ends on a pair boundary.
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void spill_store2(__amdgpu_buffer_rsrc_t rs, int lane16, int pair, double v_even,
+                                             double v_odd) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i_t, make_double2(v_even, v_odd)), rs, lane16,
+                                         pair * 1024, 0);
 }
-__device__ __forceinline__ double spill_load(__amdgpu_buffer_rsrc_t rs, int lane8, int step) {
-  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, lane8, step * 512, 0));
+__device__ __forceinline__ double2 spill_load2(__amdgpu_buffer_rsrc_t rs, int lane16, int pair) {
+  return __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, pair * 1024, 0));
 }
 
 #define WAVE_SYNC()                                        \
@@ -146,7 +166,11 @@ struct Align3Args {
   int c_lo, c_cap;  // this launch serves reads with c_lo < c <= c_cap
   int flag_above;   // ... and hands reads with c > c_cap to the exact kernel (last launch only)
   int rsh;          // log2 of the rescale period
+  int2 *rstate;      // two-launch mode: per read (K, suspect) handed from the reverse launch to the forward one
+  int read_lo;       // two-launch mode: positions [read_lo, read_lo + n_reads) of `order` are served, the spill of
+                     // position p lives in slot p - read_lo
   int *n_retry;      // reads handed to the exact kernel
+  int32_t *ties;     // per read: a path comparison fell inside the tolerance band (nvk_last_tie_flags)
   int32_t *out_events;
   int32_t *out_status;
 };
@@ -155,6 +179,10 @@ struct Align3Args {
 __device__ __forceinline__ void set_density_consts(Lane3 &l, const RowParam &o) {
   l.mean = o.mean;
   dens::scale_consts(o.ac, o.mc, l.ac, l.mc);
+  // a row whose density does not depend on the sample (transition rows, kmer_model.cpp:64-94): `mean` is
+  // not used by density() then (mc == 0) and carries the constant itself — what the paired sweeps use
+  // instead of evaluating it (PAIR below)
+  if (l.mc == 0.0) l.mean = dens::constant_density(l.ac);
 }
 
 // one block per read: RowParam rows -> per-sweep lane records
@@ -184,7 +212,7 @@ __global__ __launch_bounds__(256) void lane3_kernel(const ReadMeta *metas, const
       }
       f.mg = lane3_pack(p.mel, o.off - p.off + p.mel, adv_f);
     } else {
-      f.mean = 0.0; f.ac = 0.0; f.mc = 0.0; f.mg = lane3_pack(0, 1, 0); f.pA = 0x40000000; f.pW = 0;
+      f.mean = 1.0; f.ac = 0.0; f.mc = 0.0; f.mg = lane3_pack(0, 1, 0); f.pA = 0x40000000; f.pW = 0;
     }
     // reverse: applies step r -> r+1
     set_density_consts(b, o);
@@ -216,8 +244,35 @@ __global__ __launch_bounds__(256) void lane3_kernel(const ReadMeta *metas, const
     D = ((l).mg >> 4) & 255;                                                           \
     bs = (l).bs; pA = (l).pA; pW = (l).pW;                                             \
     ra = (int)min((unsigned)(su - D), (unsigned)(su - D + H)) * 64 + nb;               \
-    pm = melr ? 1.0 : 0.0; qm = melr ? 0.0 : 1.0;                                      \
+    if (!PAIR) { pm = melr ? 1.0 : 0.0; qm = melr ? 0.0 : 1.0; }                       \
+    if (PAIR && !em) cq = (shift_now != 0) ? ldexp((l).mean, shift_now) : (l).mean;    \
   } while (0)
+
+// The record of a lane's next row comes through the SCALAR cache when the lane switches rows (lanes that
+// switch in the same step are served one after the other; the row number is uniform then).  A vector load
+// here — this kernel prefetched the record one row ahead into registers — has to be waited for with the
+// vector-memory counter, and vector-memory operations complete in order: that wait drained every spill
+// store (reverse sweep) or spill prefetch (forward sweep) issued before it, at every row switch of any
+// lane, i.e. every ~7 steps (measured by ablation: a fifth of the kernel's time).  Scalar loads have a
+// counter of their own, and the 12 registers per lane the prefetched record occupied are free.
+__device__ __forceinline__ Lane3 lane3_sload(const Lane3 *p) {
+  typedef const __attribute__((address_space(4))) v4i_t *cptr_t;
+  cptr_t q = (cptr_t)(uintptr_t)p;
+  const v4i_t q0 = q[0], q1 = q[1], q2 = q[2];
+  Lane3 l;
+  l.mean = __hiloint2double(q0.y, q0.x);
+  l.ac = __hiloint2double(q0.w, q0.z);
+  l.mc = __hiloint2double(q1.y, q1.x);
+  l.bs = q1.z; l.end = q1.w;
+  l.lo = q2.x; l.pA = q2.y; l.pW = q2.z; l.mg = q2.w;
+  return l;
+}
+
+// exchange with the other lane of the pair (2m, 2m+1): DPP quad_perm [1,0,3,2]
+__device__ __forceinline__ int pair_swap(int v) { return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, true); }
+__device__ __forceinline__ double pair_swap(double v) {
+  return __hiloint2double(pair_swap(__double2hiint(v)), pair_swap(__double2loint(v)));
+}
 
 template <int MEL>
 __device__ __forceinline__ double emission_product(double e, double e1, double e2, double e3) {
@@ -243,8 +298,31 @@ struct Scale {
 
 // RSHC: log2 of the rescale period as a compile-time constant (the usual launch), 0: taken from the
 // launch arguments (wide-band launch)
-template <int MEL, int RSHC>
-__global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
+//
+// PAIR (model_transitions): emitting rows and transition rows alternate, so lanes 2m and 2m+1 always hold
+// one of each (64 is even: a lane's rows keep their parity).  A transition row's density is a constant,
+// so its lane has nothing to evaluate — it evaluates for its partner instead: on odd steps the emitting
+// lane evaluates its density of the next step and the partner that of the step after next (with the
+// emitting lane's row constants and sample index, refreshed by DPP whenever some lane changes rows); on
+// even steps nothing is evaluated and the two exchange their `e` registers (one DPP swap).  The
+// transition lane's own density enters its recurrence as e_eff = fma(e, pm, cq) with per-lane constants
+// (pm, cq) = (1, 0) on emitting lanes and (0, the row's constant times this step's scale move) on the
+// others — no select.  One density evaluation per lane and TWO steps instead of one per step.
+//
+// PHASE: 0 — a wave runs both sweeps of a read back to back (its spill slot is reused read after read);
+// 1 / 2 — two launches: the reverse sweeps of ALL reads of a chunk, then their forward sweeps, every read
+// with a spill slot of its own (25 GB for 10 000 config-2 reads: what 288 GB of HBM are for).  The memory
+// system then sees a pure write stream followed by a pure read stream instead of a mix (measured with
+// tools/ubench_spill.hip in this access shape: 5.5 and 5.7-6.2 TB/s against 4.3 TB/s mixed), and the
+// reverse sweep — no path search, half the registers — runs with 6 waves per SIMD instead of 4.
+#ifndef NVK_LB
+#define NVK_LB 4
+#endif
+#ifndef NVK_LB_REV
+#define NVK_LB_REV 7
+#endif
+template <int MEL, int RSHC, bool PAIR, int PHASE>
+__global__ __launch_bounds__(64, PHASE == 1 ? NVK_LB_REV : NVK_LB) void align3_kernel(Align3Args g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double *etab = reinterpret_cast<double *>(smem);
   double *ring = etab + ETN;
@@ -253,53 +331,61 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
   // entry H*64 of both arrays is a permanent zero: a lane whose predecessor cell lies outside the
   // predecessor's band reads it instead of masking what it read (one select on the index instead of
   // one per loaded register)
+  // (the reverse-only launch keeps 8 bytes per lane and slot: its zero entry is hist[H*64])
   int *ghist = reinterpret_cast<int *>(hist2 + (size_t)g.H * 64 + 1);
-  int *s_read = ghist + (size_t)g.H * 64 + 1;
+  int *s_read = (PHASE == 1) ? reinterpret_cast<int *>(hist + (size_t)g.H * 64 + 1) : ghist + (size_t)g.H * 64 + 1;
 
   const int lane = threadIdx.x;
   const int H = g.H, RM = g.SR - 1;
-  // (0x00020000: raw 32-bit data format, no swizzle; the range check is left wide open — the slot's size
-  // bounds every offset by construction)
-  const __amdgpu_buffer_rsrc_t spill_rs = __builtin_amdgcn_make_buffer_rsrc(
-      g.spill_v + (size_t)blockIdx.x * g.spill_stride, 0, 0x7ffffff0, 0x00020000);
-  int32_t *spill_L = g.spill_L + (size_t)blockIdx.x * g.L_stride;
   uint32_t *bp = g.bp + (size_t)blockIdx.x * g.bp_stride;
 
   for (int q = lane; q < g.SR; q += 64) ring[q] = 0.0;
   dens::fill_table(etab, lane, 64);
   const int HZ = H * 64;
   if (lane == 0) {
-    hist2[HZ] = make_double2(0.0, 0.0);
-    ghist[HZ] = 0;
+    if (PHASE == 1) {
+      hist[HZ] = 0.0;
+    } else {
+      hist2[HZ] = make_double2(0.0, 0.0);
+      ghist[HZ] = 0;
+    }
   }
   // per-lane constants kept in vector registers (the compiler would otherwise rebuild them from scalars
   // with one or two VOP3 instructions at every use): byte offsets of the lane inside a history slot and
   // the indices of the zero entry
   unsigned char *histb = reinterpret_cast<unsigned char *>(hist2);
   unsigned char *ghistb = reinterpret_cast<unsigned char *>(ghist);
-  int lane16 = lane * 16, lane8 = lane * 8, HZv = HZ, HZ2v = 2 * HZ;
+  int lane16 = lane * 16, lane8 = lane * 8, HZv = HZ, HZ2v = (PHASE == 1) ? HZ : 2 * HZ;
   asm volatile("" : "+v"(lane16), "+v"(lane8), "+v"(HZv), "+v"(HZ2v));
 
   while (true) {
     __syncthreads();
     if (lane == 0) *s_read = atomicAdd(g.counter, 1);
     __syncthreads();
-    const int pos = __builtin_amdgcn_readfirstlane(*s_read);
-    if (pos >= g.n_reads) break;
+    const int pos0 = __builtin_amdgcn_readfirstlane(*s_read);
+    if (pos0 >= g.n_reads) break;
+    const int pos = pos0 + ((PHASE == 0) ? 0 : g.read_lo);
     const int rd = g.order ? g.order[pos] : pos;
     const ReadMeta m = g.metas[rd];
     if (m.status != NVK_READ_OK) {
-      if (lane == 0) g.out_status[rd] = m.status;
+      if (PHASE != 1 && lane == 0) g.out_status[rd] = m.status;
       continue;
     }
     if (m.c <= g.c_lo) continue;  // served by the launch with the smaller rings
     if (m.c > g.c_cap) {           // band too wide for this launch's LDS rings
-      if (g.flag_above && lane == 0) {
+      if (PHASE != 1 && g.flag_above && lane == 0) {
         g.out_status[rd] = NVK_READ_RETRY_INTERNAL;
         atomicAdd(g.n_retry, 1);
       }
       continue;
     }
+    // the spill slot: the wave's own (one-launch mode) or the read's (two launches)
+    // (0x00020000: raw 32-bit data format, no swizzle; the range check is left wide open — the slot's size
+    // bounds every offset by construction)
+    const size_t slot = (PHASE == 0) ? (size_t)blockIdx.x : (size_t)pos0;
+    const __amdgpu_buffer_rsrc_t spill_rs = __builtin_amdgcn_make_buffer_rsrc(
+        g.spill_v + slot * g.spill_stride, 0, 0x7ffffff0, 0x00020000);
+    int32_t *spill_L = g.spill_L + slot * g.L_stride;
     const int T = __builtin_amdgcn_readfirstlane(m.T);
     const int N = __builtin_amdgcn_readfirstlane(m.N);
     const int c = __builtin_amdgcn_readfirstlane(m.c);
@@ -312,38 +398,46 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
     const double *sig = g.signal + m.sig_off;
     const int top = T - 1;
     int K = 0;          // true exponent of the largest suffix[0][.]
+#if NVK_PAIR_DEBUG == 2
+    int dbg_left = 6;
+#endif
     bool suspect = false;  // something left the double range: the exact kernel must redo this read
     const int RSH = RSHC ? RSHC : g.rsh, RS = 1 << RSH;
 
     // =========================== reverse sweep: suffix rows -> spill ===========================
-    {
+    if (PHASE != 2) {
       int r = top - ((top - lane) & 63);
       // Lanes without a row keep bs = hi = -big: never active, never finished.  For the other
       // rows `hi` already folds the "predecessor column exists" test (i + mel <= N).
       double mean = 0, ac2 = 0, mc2 = 0;
       int bs = -0x40000000, hi = -0x40000000, pA = 0x40000000, pW = 0, melr = 0, D = 1;
       double pm = 0.0, qm = 1.0;
+      // PAIR: emitting lanes of the reverse sweep are the even ones (row r applies step r -> r+1)
+      const bool em = PAIR ? ((lane & 1) == 0) : true;
+      double cq = 0.0;   // PAIR: the transition lane's own (constant) density times this step's scale move
+      int ia = 0;        // PAIR: sample index of the lane's next density evaluation
+      int dsel = 0;      // PAIR: scale move applied by that evaluation (emitting lanes, rescale steps only)
+      int shift_now = 0; // scale move of the current step (uniform)
+      if (PAIR) { pm = em ? 1.0 : 0.0; qm = em ? 0.0 : 1.0; }
       int su = 0;                       // history slot written at this step
       const int nb = (lane + 1) & 63;   // the lane the values come from
       int ra = (H - 1) * 64 + nb;       // read index into the history ring, advanced with su
       bool is_init = false;
-      Lane3 nx;  // the lane's next row (r - 64), fetched one row ahead
-      nx.mean = nx.ac = nx.mc = 0.0; nx.bs = nx.end = nx.lo = nx.pA = nx.pW = nx.mg = 0;
       int i = t_max;
       if (r >= 0) {
         const Lane3 cu = revl[r];
         TAKE_LANE(cu);
         hi = cu.end;
         is_init = (r == top);
-        if (r >= 64) nx = revl[r - 64];
         i = t_max - offs[r];
       }
       double prev = 0.0, e1 = 1.0, e2 = 1.0, e3 = 1.0;
+      double o_hold = 0.0;  // the value of the even step of a trip, stored together with the odd step's
       int kmax = -0x40000000;
       int r_old = top;
       int i_old = __builtin_amdgcn_readlane(i, top & 63);  // sample index of the oldest open row (scalar)
       int filled_lo = (i_old / CH + 1) * CH;
-      while (i_old - 1 < filled_lo) {
+      while (i_old - 3 < filled_lo) {
         filled_lo -= CH;
         for (int q = lane; q < CH; q += 64) {
           int idx = filled_lo + q;
@@ -353,7 +447,19 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
       __syncthreads();
       Scale sc{0, 0, 0};
       int sh_until = 0;  // (scalar) steps below this one still see values from before the last scale move
-      double e = density(ring[i & RM], mean, ac2, mc2, 0, etab);
+      // (pair_swap only ever under full exec, never inside a conditional operand: a DPP read of a
+      // disabled lane returns 0)
+      const int ip0 = PAIR ? pair_swap(i) : 0;
+      if (PAIR) {  // the partner's row constants and sample index (see the row switch below)
+        const double pmn = pair_swap(mean), pac = pair_swap(ac2), pmc = pair_swap(mc2);
+        if (!em) { mean = pmn; ac2 = pac; mc2 = pmc; }
+        // step 0 is even: the transition lane holds its partner's density of step 1, sample s[ip - 1]
+        ia = em ? i : ip0 - 1;
+      } else {
+        ia = i;
+      }
+      double e = density(ring[ia & RM], mean, ac2, mc2, 0, etab);
+      if (PAIR) ia = (em ? i - 1 : ip0 - 2) - 1;  // first evaluation at step 1
       int init_live = 1;  // (uniform, a scalar register) the last row is still being swept
       int row0_live = (__builtin_amdgcn_readfirstlane(r) == 0) ? 1 : 0;  // lane 0 is on row 0
 
@@ -372,33 +478,57 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
           sc.d_last = sc.d_next;
           sh_until = (sc.d_next != 0) ? u + c + MEL : 0;
           sc.d_next = 0;
+          if (PAIR) { cq = ldexp(cq, sc.d_last); dsel = 0; }  // (0 stays 0 on emitting lanes)
         }
+        if (PAIR && age == 1 && u > 1) cq = ldexp(cq, -sc.d_last);  // exact: the constant is back
+        shift_now = (age == 0 && u > 0) ? sc.d_last : 0;
         bool fin = (i < bs);
         if (__any(fin)) {
-          if (fin) {
-            r -= 64;
-            i += nx.mg >> 12;
-            prev = 0.0;
-            if (r >= 0) {
-              TAKE_LANE(nx);
-              hi = nx.end;
-              is_init = false;
-              e = density(ring[i & RM], mean, ac2, mc2, (age == 0 && u > 0) ? sc.d_last : 0, etab);
-            } else {
-              hi = -0x40000000; bs = -0x40000000; pA = 0x40000000; pW = 0;
+          bool redo = false;  // this lane must re-evaluate the density its `e` stands for
+          for (unsigned long long fm = __builtin_amdgcn_ballot_w64(fin); fm != 0; fm &= fm - 1) {
+            const int fl = __builtin_ctzll(fm);
+            const int rn = __builtin_amdgcn_readlane(r, fl) - 64;  // (uniform) the row that lane takes
+            Lane3 nx;
+            nx.mean = nx.ac = nx.mc = 0.0; nx.bs = nx.end = nx.lo = nx.pA = nx.pW = nx.mg = 0;
+            if (rn >= 0) nx = lane3_sload(revl + rn);
+            if (lane == fl) {
+              r = rn;
+              i += nx.mg >> 12;
+              prev = 0.0;
+              if (r >= 0) {
+                TAKE_LANE(nx);
+                hi = nx.end;
+                is_init = false;
+                redo = true;
+              } else {
+                hi = -0x40000000; bs = -0x40000000; pA = 0x40000000; pW = 0;
+                if (PAIR && !em) cq = 0.0;
+              }
             }
           }
-          // Every lane (re)fetches its next row here, not only the lanes that switched: a load under
-          // a divergent branch is copied into the loop-carried registers right away, which would
-          // expose its full latency at every switch.
-          nx = revl[max(r - 64, 0)];
+          if (PAIR) {
+            // every transition lane takes its partner's (possibly new) row constants and sample index;
+            // on an even step its `e` is the partner's density of the NEXT step, evaluated one step ago
+            // with the constants of then: evaluate it again (the same value unless the partner switched)
+            const double pmn = pair_swap(mean), pac = pair_swap(ac2), pmc = pair_swap(mc2);
+            const int ip = pair_swap(i);
+            if (!em) { mean = pmn; ac2 = pac; mc2 = pmc; }
+            const int odd = u & 1;
+            redo = em ? redo : !odd;
+            if (redo) e = density(ring[(em ? i : ip - 1) & RM], mean, ac2, mc2, em ? shift_now : 0, etab);
+            ia = (em ? i - 1 : ip - 2) - (odd ? 0 : 1);
+          } else if (redo) {
+            e = density(ring[i & RM], mean, ac2, mc2, shift_now, etab);
+          }
           while (r_old >= 0 && __builtin_amdgcn_readlane(r, r_old & 63) != r_old) r_old--;
           i_old = __builtin_amdgcn_readlane(i, r_old & 63);
           init_live &= (__builtin_amdgcn_readlane(r, top & 63) == top) ? 1 : 0;
           row0_live = (__builtin_amdgcn_readfirstlane(r) == 0) ? 1 : 0;
         }
         if (r_old >= 0) {
-          const int need_min = i_old - 2;  // (a younger row may be one sample beyond the oldest one)
+          // (a younger row may be one sample beyond the oldest one; PAIR: and its partner evaluates one
+          // sample further ahead)
+          const int need_min = i_old - (PAIR ? 3 : 2);
           while (need_min < filled_lo) {
             filled_lo -= CH;
             __syncthreads();
@@ -409,16 +539,39 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
             __syncthreads();
           }
         }
+#if NVK_PAIR_DEBUG == 2
+        if (PAIR && blockIdx.x == 0 && dbg_left > 0) {
+          const double chk = density(ring[i & RM], mean, ac2, mc2, shift_now, etab);
+          const bool badl = em && r >= 0 && i <= hi && i >= bs && chk != e;
+          if (__any(badl)) {
+            dbg_left--;
+            if (badl) printf("rev rd=%d u=%d lane=%d r=%d i=%d e=%.17g chk=%.17g age=%d shift=%d dnext=%d\n", rd, u, lane, r, i, e, chk, age, shift_now, sc.d_next);
+          }
+        }
+#endif
         // LDS reads first: the neighbour's value and the sample of the next step's density
         // the neighbour's value is D = gap + mel steps old: slot (su - D) mod H
         // outside the predecessor's band: the zero entry
         const int hs = ((unsigned)(i - pA) <= (unsigned)pW) ? ra : HZ2v;
-        const double xn = ring[(i - 1) & RM];
+        const bool evalstep = !PAIR || NVK_PAIR_DEBUG == 1 || (uq & 1);  // (static) PAIR: densities are evaluated on odd steps
+        double xn = 0.0;
+#if NVK_ABL == 6
+        if (evalstep) xn = (double)i * 1e-3;
+#else
+        if (evalstep) xn = ring[((PAIR && NVK_PAIR_DEBUG != 1) ? ia : i - 1) & RM];
+#endif
+#if NVK_ABL == 3
+        const double pv = prev * 0.5;
+#elif NVK_ABL == 10
+        const double pv = (uq & 1) ? prev * 0.5 : hist[hs];
+#else
         const double pv = hist[hs];
+#endif
         // scalar shifts that bring a neighbour value from D steps ago to the current scale
         // a rescale lies between the step a neighbour value was produced at and now?  (rare, uniform)
         const bool sh_any = (u < sh_until);
-        const DensHalf dn = density_begin(xn, mean, ac2, mc2, etab);
+        DensHalf dn;
+        if (evalstep) dn = density_begin(xn, mean, ac2, mc2, etab);
         // ---- the cell (r, i): out = P * pred[i + mel] + e(s[i]) * out[i + 1]
 #define ACTIVE_R ((i <= hi) && (i >= bs))
         double P = emission_product<MEL>(e, e1, e2, e3);
@@ -428,7 +581,8 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
           asm volatile("");
           t1 = ldexp(t1, ((age < D) ? sc.d_last : 0) - ((age < melr) ? sc.d_last : 0));
         }
-        double o = fma(e, prev, t1);  // zero outside the lane's span, see Lane3::pA
+        const double ee = PAIR ? fma(e, pm, cq) : e;  // the transition lane's own density is its constant
+        double o = fma(ee, prev, t1);  // zero outside the lane's span, see Lane3::pA
         if (init_live) {
           asm volatile("");
           if (is_init) o = ACTIVE_R ? ldexp(1.0, sc.L) : 0.0;
@@ -441,8 +595,19 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
           asm volatile("");
           if (o != 0.0) kmax = max(kmax, __builtin_amdgcn_frexp_exp(o) - sc.L);
         }
+#if NVK_ABL == 10
+        if (!(uq & 1)) *reinterpret_cast<double *>(histb + (su * 512 + lane8)) = o;
+#elif NVK_ABL != 7
         *reinterpret_cast<double *>(histb + (su * 512 + lane8)) = o;
-        spill_store(spill_rs, lane8, t - t_min, o);
+#endif
+        // (n_steps is even: an odd u is the even step 2p of the forward order, the step before it 2p + 1)
+        if (uq & 1) {
+#if NVK_ABL != 4 && NVK_ABL != 8
+          spill_store2(spill_rs, lane16, (t - t_min) >> 1, o, o_hold);
+#endif
+        } else {
+          o_hold = o;
+        }
         if (age == 0) {  // the scale only moves on these steps
           asm volatile("");  // (a scalar branch first: the lane test need not run at every step)
           if (lane == 0) spill_L[u >> RSH] = sc.L;
@@ -456,25 +621,50 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
           int mx = wave_max_i(ex);
           sc.d_next = (mx > -0x40000000) ? min(TARGET - mx, DMAX) : 0;
           suspect |= (mx > -0x40000000) && (TARGET - mx > DMAX);
+          if (PAIR) dsel = em ? sc.d_next : 0;  // (RS - 1 is odd: an evaluation step)
         }
         i -= 1;
         i_old -= 1;
         e3 = e2; e2 = e1; e1 = e;
-        e = density_end(dn, sc.d_next);
+        if (!PAIR || NVK_PAIR_DEBUG == 1) {
+          e = density_end(dn, sc.d_next);
+        } else if (evalstep) {
+          e = density_end(dn, dsel);  // emitting lane: its next step; partner: the step after next
+          ia -= 2;
+        } else {
+          e = pair_swap(e);  // the emitting lane takes what its partner evaluated one step ago
+        }
         su = (su + 1 == H) ? 0 : su + 1;
         ra = (int)min((unsigned)(ra + 64), (unsigned)(ra + 64 - HZ));
+#if NVK_ABL == 10
+        if (uq & 1) WAVE_SYNC();
+#elif NVK_ABL != 2
         WAVE_SYNC();
+#endif
       }
       }
       K = __builtin_amdgcn_readfirstlane(kmax);
       if (K == -0x40000000) K = 0;
     }
+    if (PHASE == 1) {  // hand K and the range guard's verdict to the forward launch
+      const bool any_s = __any(suspect);
+      if (lane == 0) g.rstate[rd] = make_int2(K, any_s ? 1 : 0);
+      continue;
+    }
+    if (PHASE == 2) {
+      const int2 rs = g.rstate[rd];
+      K = __builtin_amdgcn_readfirstlane(rs.x);
+      suspect = (rs.y != 0);
+    }
     __syncthreads();  // (also drains the stores)
     __builtin_amdgcn_s_dcache_inv();
 
     // ================= forward sweep: prefix rows, posterior, path DP, update bits =================
+    // arg-max of the last row: best score, its margin, its scale, its cell (in registers: kept in LDS, read
+    // and written by the last row's lane only, it cost 4 % — one more LDS round trip on that row's steps)
     double fbest = 0.0, fthr = 0.0;
     int fidx = -1, fG = 0;
+    unsigned long long amb = 0;  // (scalar) lanes that saw a comparison inside the tolerance band
     {
       int r = lane;
       // Lanes without a row keep lo = be = +big: never active, never finished.  For the other rows
@@ -482,19 +672,21 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
       double mean = 0, ac2 = 0, mc2 = 0;
       int bs = 0, be = 0x40000000, lo = 0x40000000, pA = 0x40000000, pW = 0, melr = 0, D = 1;
       double pm = 0.0, qm = 1.0;
+      // PAIR: emitting lanes of the forward sweep are the odd ones (row r applies step r-1 -> r)
+      const bool em = PAIR ? ((lane & 1) != 0) : true;
+      double cq = 0.0;
+      int ia = 0, dsel = 0, shift_now = 0;  // see the reverse sweep
+      if (PAIR) { pm = em ? 1.0 : 0.0; qm = em ? 0.0 : 1.0; }
       int su = 0;
       const int nb = (lane - 1) & 63;
       int ra = (H - 1) * 64 + nb;
       bool is_init = false;
-      Lane3 nx;  // the lane's next row (r + 64), fetched one row ahead
-      nx.mean = nx.ac = nx.mc = 0.0; nx.bs = nx.end = nx.lo = nx.pA = nx.pW = nx.mg = 0;
       int i = t_min - 64 * c;
       if (r < T) {
         const Lane3 cu = fwdl[r];
         TAKE_LANE(cu);
         be = cu.end; lo = cu.lo;
         is_init = (r == 0);
-        if (r + 64 < T) nx = fwdl[r + 64];
         i = t_min - offs[r];
       }
       double prev = 0.0, e1 = 1.0, e2 = 1.0, e3 = 1.0;
@@ -511,7 +703,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
       int r_old = 0;
       int i_old = t_min;  // sample index of the oldest open row (scalar): offs[0] = 0
       int filled_hi = ((t_min - MEL - 1) > 0 ? (t_min - MEL - 1) / CH : 0) * CH;
-      while (t_min + 1 >= filled_hi) {
+      while (t_min + 2 >= filled_hi) {
         for (int w = lane; w < CH; w += 64) {
           int idx = filled_hi + w;
           ring[idx & RM] = (idx >= 0 && idx < N) ? sig[idx] : 0.0;
@@ -521,13 +713,23 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
       __syncthreads();
       Scale sc{0, 0, 0};
       int sh_until = 0;  // (scalar) steps below this one still see values from before the last scale move
-      double e = density(ring[(i - 1) & RM], mean, ac2, mc2, 0, etab);
+      const int ip0 = PAIR ? pair_swap(i) : 0;
+      if (PAIR) {
+        const double pmn = pair_swap(mean), pac = pair_swap(ac2), pmc = pair_swap(mc2);
+        if (!em) { mean = pmn; ac2 = pac; mc2 = pmc; }
+        // step 0 is even: the transition lane holds its partner's density of step 1, sample s[ip]
+        ia = em ? i - 1 : ip0;
+      } else {
+        ia = i - 1;
+      }
+      double e = density(ring[ia & RM], mean, ac2, mc2, 0, etab);
+      if (PAIR) ia = (em ? i : ip0 + 1) + 1;  // first evaluation at step 1
       int init_live = 1;  // (uniform, scalar registers) row 0 is still being swept
       int top_live = (top < 64) ? 1 : 0;  // the last row has been started
 
-      double cur_v[PF];
+      double2 cur_v[PF / 2];
 #pragma unroll
-      for (int q = 0; q < PF; q++) cur_v[q] = spill_load(spill_rs, lane8, q);
+      for (int q = 0; q < PF / 2; q++) cur_v[q] = spill_load2(spill_rs, lane16, q);
       // The reverse sweep's scale, one value per RS steps, comes through the scalar cache: it is
       // uniform, and a vector load per step would put one more operation on the wait counter that
       // guards the spill prefetch.  The cache was invalidated after the reverse sweep's stores.
@@ -549,34 +751,56 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
               sc.d_last = sc.d_next;
               sh_until = (sc.d_next != 0) ? u + c + MEL : 0;
               sc.d_next = 0;
+              if (PAIR) { cq = ldexp(cq, sc.d_last); dsel = 0; }
             }
+            if (PAIR && age == 1 && u > 1) cq = ldexp(cq, -sc.d_last);
+            shift_now = (age == 0 && u > 0) ? sc.d_last : 0;
             bool fin = (i > be);
             if (__any(fin)) {
-              if (fin) {
-                smin = fmin(smin, rsum);
-                smax = fmax(smax, rsum);
-                rsum = 0.0;
-                r += 64;
-                i -= nx.mg >> 12;
-                prev = 0.0;
-                bestn = 0.0; bthr = 0.0; G = GBIG;
-                if (r < T) {
-                  TAKE_LANE(nx);
-                  be = nx.end; lo = nx.lo;
-                  is_init = false;
-                  e = density(ring[(i - 1) & RM], mean, ac2, mc2, (age == 0 && u > 0) ? sc.d_last : 0, etab);
-                } else {
-                  lo = 0x40000000; be = 0x40000000; pA = 0x40000000; pW = 0;
+              bool redo = false;
+              for (unsigned long long fm = __builtin_amdgcn_ballot_w64(fin); fm != 0; fm &= fm - 1) {
+                const int fl = __builtin_ctzll(fm);
+                const int rn = __builtin_amdgcn_readlane(r, fl) + 64;  // (uniform) the row that lane takes
+                Lane3 nx;
+                nx.mean = nx.ac = nx.mc = 0.0; nx.bs = nx.end = nx.lo = nx.pA = nx.pW = nx.mg = 0;
+                if (rn < T) nx = lane3_sload(fwdl + rn);
+                if (lane == fl) {
+                  smin = fmin(smin, rsum);
+                  smax = fmax(smax, rsum);
+                  rsum = 0.0;
+                  r = rn;
+                  i -= nx.mg >> 12;
+                  prev = 0.0;
+                  bestn = 0.0; bthr = 0.0; G = GBIG;
+                  if (r < T) {
+                    TAKE_LANE(nx);
+                    be = nx.end; lo = nx.lo;
+                    is_init = false;
+                    redo = true;
+                  } else {
+                    lo = 0x40000000; be = 0x40000000; pA = 0x40000000; pW = 0;
+                    if (PAIR && !em) cq = 0.0;
+                  }
                 }
               }
-              nx = fwdl[min(r + 64, top)];  // all lanes, see the reverse sweep
+              if (PAIR) {  // see the reverse sweep
+                const double pmn = pair_swap(mean), pac = pair_swap(ac2), pmc = pair_swap(mc2);
+                const int ip = pair_swap(i);
+                if (!em) { mean = pmn; ac2 = pac; mc2 = pmc; }
+                const int odd = u & 1;
+                redo = em ? redo : !odd;
+                if (redo) e = density(ring[(em ? i - 1 : ip) & RM], mean, ac2, mc2, em ? shift_now : 0, etab);
+                ia = (em ? i : ip + 1) + (odd ? 0 : 1);
+              } else if (redo) {
+                e = density(ring[(i - 1) & RM], mean, ac2, mc2, shift_now, etab);
+              }
               while (r_old < T && __builtin_amdgcn_readlane(r, r_old & 63) != r_old) r_old++;
               i_old = __builtin_amdgcn_readlane(i, r_old & 63);
               init_live &= (__builtin_amdgcn_readfirstlane(r) == 0) ? 1 : 0;
               top_live = (__builtin_amdgcn_readlane(r, top & 63) == top) ? 1 : 0;
             }
             if (r_old < T) {
-              const int need_max = i_old + 1;
+              const int need_max = i_old + (PAIR ? 2 : 1);  // (PAIR: the partner evaluates one sample further ahead)
               while (need_max >= filled_hi) {
                 __syncthreads();
                 for (int w = lane; w < CH; w += 64) {
@@ -587,13 +811,35 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
                 __syncthreads();
               }
             }
+#if NVK_PAIR_DEBUG == 2
+            if (PAIR && blockIdx.x == 0 && dbg_left > 0) {
+              const double chk = density(ring[(i - 1) & RM], mean, ac2, mc2, shift_now, etab);
+              const bool badl = em && r < T && i >= lo && i <= be && chk != e;
+              if (__any(badl)) {
+                dbg_left--;
+                if (badl) printf("fwd rd=%d u=%d lane=%d r=%d i=%d e=%.17g chk=%.17g age=%d shift=%d dnext=%d\n", rd, u, lane, r, i, e, chk, age, shift_now, sc.d_next);
+              }
+            }
+#endif
             // LDS reads first: the neighbour's values and the sample of the next step's density
             const int hs = ((unsigned)(i - pA) <= (unsigned)pW) ? ra : HZv;  // else: the zero entry
-            const double xn = ring[i & RM];
+            const bool evalstep = !PAIR || NVK_PAIR_DEBUG == 1 || (q & 1);  // (static) PAIR: densities are evaluated on odd steps
+            double xn = 0.0;
+#if NVK_ABL == 6
+            if (evalstep) xn = (double)i * 1e-3;
+#else
+            if (evalstep) xn = ring[((PAIR && NVK_PAIR_DEBUG != 1) ? ia : i) & RM];
+#endif
+#if NVK_ABL == 3
+            const double2 hv = make_double2(prev * 0.5, bestn);
+            const int Gin = G;
+#else
             const double2 hv = hist2[hs];
             const int Gin = ghist[hs];
+#endif
             const bool sh_any = (u < sh_until);
-            const DensHalf dn = density_begin(xn, mean, ac2, mc2, etab);
+            DensHalf dn;
+            if (evalstep) dn = density_begin(xn, mean, ac2, mc2, etab);
             // ---- the cell (r, i): out = P * pred[i - mel] + e(s[i-1]) * out[i - 1]
             // (the band test is only needed on the rare paths below: outside the band the posterior is zero
             // by itself, see `post`, and outside the lane's span its value is, see Lane3::pA)
@@ -606,14 +852,15 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
               asm volatile("");
               t1 = ldexp(t1, ((age < D) ? sc.d_last : 0) - ((age < melr) ? sc.d_last : 0));
             }
-            double o = fma(e, prev, t1);
+            const double ee = PAIR ? fma(e, pm, cq) : e;
+            double o = fma(ee, prev, t1);
             if (init_live) {
               asm volatile("");
               if (is_init) o = IN_BAND ? ldexp(1.0, sc.L) : 0.0;
             }
             prev = o;
             // ---- posterior of the cell, on the scale 2^-K:  post = prefix * suffix
-            const double suf = cur_v[q];
+            const double suf = (q & 1) ? cur_v[q >> 1].y : cur_v[q >> 1].x;
             const int ur = n_steps - 1 - u;  // the reverse sweep's step for this anti-diagonal
             if ((ur & (RS - 1)) == RS - 1 || u == 0) Lrev = sL[ur >> RSH];
             const int kap = -(sc.L + K) - Lrev;  // scalar
@@ -628,8 +875,22 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
             // Scores are (double, integer scale): stored = true * 2^scale.  The running maximum is kept
             // normalised (bestn in [0.5,1), scale G); an incoming score is brought onto that scale
             // before comparing (far below -> 0, far above -> inf, both compare correctly).
+#if NVK_ABL == 5
+            const double dva = dv;
+#else
             const double dva = ldexp(dv, G - Gin);  // no maximum yet: G = GBIG, any dv > 0 becomes +inf
-            const bool upd = (dva - bestn > bthr);  // (dv == 0 outside the span: never an update)
+#endif
+            const double tdiff = dva - bestn;
+            const bool upd = (tdiff > bthr);  // (dv == 0 outside the span: never an update)
+            // The tie flag (include/nadavca_hip.h, parity contract): the two scores are closer than 2^-24
+            // relative — far more than the rounding either this engine or the reference accumulates, so a
+            // read without the flag has the reference's decisions everywhere.  (A candidate of 0, or the
+            // +inf a first candidate turns into, never qualifies.  Scores of cells thousands of bits below
+            // the path would tie by their lost precision: this file is compiled with FP64 denormals
+            // flushed, which makes them exact zeros.)
+#if !NVK_NO_TIEFLAG
+            amb |= __builtin_amdgcn_ballot_w64(fabs(tdiff) < dva * 0x1.0p-24);
+#endif
             if (upd) {
               bestn = __builtin_amdgcn_frexp_mant(dv);         // in [0.5, 1)
               G = Gin - __builtin_amdgcn_frexp_exp(dv);        // its scale; -G = true exponent
@@ -645,6 +906,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
             if (top_live) {
               asm volatile("");
               const double da = ldexp(dpv, (fbest == 0.0) ? 0 : fG - Gd);
+              amb |= __builtin_amdgcn_ballot_w64(r == top && IN_BAND && fabs(da - fbest) < da * 0x1.0p-24);
               if (r == top && IN_BAND && (da - fbest > fthr)) {
                 fbest = dpv;
                 fG = Gd;
@@ -652,8 +914,10 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
                 fthr = dpv * ((double)abs(__builtin_amdgcn_frexp_exp(dpv) - Gd) * 0x1.0p-52);
               }
             }
+#if NVK_ABL != 7
             *reinterpret_cast<double2 *>(histb + (su * 1024 + lane16)) = make_double2(o, dpv);
             *reinterpret_cast<int *>(ghistb + (su * 256 + (lane16 >> 2))) = Gd;
+#endif
             if ((u & 31) == 31 || u == n_steps - 1) {
               int w = u >> 5;
               asm volatile("" : "+s"(w));  // keeps the address arithmetic inside the branch
@@ -661,22 +925,34 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
               bits = 0;
             }
             // refill the prefetch slot just consumed
-            cur_v[q] = spill_load(spill_rs, lane8, u + PF);
+#if NVK_ABL != 4 && NVK_ABL != 9
+            if (q & 1) cur_v[q >> 1] = spill_load2(spill_rs, lane16, (u + PF) >> 1);
+#endif
             // ---- rescale decision for the next step, then the next step's density
             if (age == RS - 1) {
               suspect |= !(o <= HUGE_V);
               int ex = (o != 0.0) ? __builtin_amdgcn_frexp_exp(o) : -0x40000000;
               int mx = wave_max_i(ex);
               sc.d_next = (mx > -0x40000000) ? min(TARGET - mx, DMAX) : 0;
-          suspect |= (mx > -0x40000000) && (TARGET - mx > DMAX);
+              suspect |= (mx > -0x40000000) && (TARGET - mx > DMAX);
+              if (PAIR) dsel = em ? sc.d_next : 0;
             }
             i += 1;
             i_old += 1;
             e3 = e2; e2 = e1; e1 = e;
-            e = density_end(dn, sc.d_next);
+            if (!PAIR || NVK_PAIR_DEBUG == 1) {
+              e = density_end(dn, sc.d_next);
+            } else if (evalstep) {
+              e = density_end(dn, dsel);
+              ia += 2;
+            } else {
+              e = pair_swap(e);
+            }
             su = (su + 1 == H) ? 0 : su + 1;
             ra = (int)min((unsigned)(ra + 64), (unsigned)(ra + 64 - HZ));
+#if NVK_ABL != 2
             WAVE_SYNC();
+#endif
           }
         }
       }
@@ -707,6 +983,7 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
       if (lane == 0) g.out_status[rd] = NVK_READ_NO_PATH;
       continue;
     }
+    if (lane == 0 && amb != 0) g.ties[rd] = 1;
     if (lane == 0) {
       int32_t *ev = g.out_events + 2 * m.ref_off;
       int st = NVK_READ_OK;
@@ -742,6 +1019,15 @@ __global__ __launch_bounds__(64) void align3_kernel(Align3Args g) {
   }
 }
 
+// steps of the reads in the order they are handed out (two-launch mode: sizes the per-read spill slots)
+__global__ void gather_steps_kernel(const ReadMeta *metas, const int *order, int n, int32_t *out) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n) {
+    const ReadMeta m = metas[order[p]];
+    out[p] = (m.status == NVK_READ_OK) ? m.pad : 0;
+  }
+}
+
 }  // namespace
 
 int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadMeta *metas,
@@ -770,15 +1056,40 @@ int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadM
   int *d_retry = counter + 2;
   NVK_HIP(hipMemsetAsync(counter, 0, 4 * sizeof(int), ctx->stream));
 
-  void (*kern16)(Align3Args) = nullptr;  // rescale period 16 compiled in
-  void (*kernv)(Align3Args) = nullptr;   // period from the arguments
+  // kernels: [0] both sweeps in one wave, [1] reverse sweeps, [2] forward sweeps; rescale period 16
+  // compiled in (k16) or taken from the arguments (kv).  With transition rows: the paired variant (one
+  // density evaluation per lane pair and step).
+#ifndef NVK_NO_PAIR
+#define NVK_NO_PAIR 0  // (development switch, tools/build_variant.sh -DNVK_NO_PAIR=1)
+#endif
+#ifndef NVK_TWO_PHASE
+#define NVK_TWO_PHASE 1  // (development switch: 0 = the one-launch form)
+#endif
+  void (*k16[3])(Align3Args) = {nullptr, nullptr, nullptr};
+  void (*kv[3])(Align3Args) = {nullptr, nullptr, nullptr};
+#if NVK_TWO_PHASE
+#define A3_SET(M, P)                                                                           \
+  do {                                                                                         \
+    k16[1] = align3_kernel<M, 4, P, 1>; k16[2] = align3_kernel<M, 4, P, 2>;                    \
+    kv[1] = align3_kernel<M, 0, P, 1>; kv[2] = align3_kernel<M, 0, P, 2>;                      \
+  } while (0)
+#else
+#define A3_SET(M, P)                                                                           \
+  do { k16[0] = align3_kernel<M, 4, P, 0>; kv[0] = align3_kernel<M, 0, P, 0>; } while (0)
+#endif
+#define A3_PICK(M)                                                                             \
+  do {                                                                                         \
+    if (transitions && !NVK_NO_PAIR) A3_SET(M, true); else A3_SET(M, false);                   \
+  } while (0)
   switch (mel) {
-    case 0: kern16 = align3_kernel<0, 4>; kernv = align3_kernel<0, 0>; break;
-    case 1: kern16 = align3_kernel<1, 4>; kernv = align3_kernel<1, 0>; break;
-    case 2: kern16 = align3_kernel<2, 4>; kernv = align3_kernel<2, 0>; break;
-    case 3: kern16 = align3_kernel<3, 4>; kernv = align3_kernel<3, 0>; break;
-    default: kern16 = align3_kernel<4, 4>; kernv = align3_kernel<4, 0>; break;
+    case 0: A3_PICK(0); break;
+    case 1: A3_PICK(1); break;
+    case 2: A3_PICK(2); break;
+    case 3: A3_PICK(3); break;
+    default: A3_PICK(4); break;
   }
+#undef A3_PICK
+#undef A3_SET
   {
     TimerScope ts(ctx, NVK_K_PLAN);
     hipLaunchKernelGGL(lane3_kernel, dim3((unsigned)a.n_reads), dim3(256), 0, ctx->stream, metas, rows,
@@ -801,6 +1112,27 @@ int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadM
   if (a.n_reads - n_wide > 0 || max_c <= ALIGN1_C_CAP)
     cls[ncls++] = Cls{0, max_c < ALIGN1_C_CAP ? max_c : ALIGN1_C_CAP, a.n_reads - n_wide};
   if (max_c > ALIGN1_C_CAP) cls[ncls++] = Cls{ALIGN1_C_CAP, max_c < C_HARD ? max_c : C_HARD, n_wide};
+#if NVK_TWO_PHASE
+  // steps of the reads in launch order (longest first, bucket by bucket): sizes the per-read spill slots
+  std::vector<int32_t> steps_sorted;
+  try {
+    steps_sorted.resize((size_t)a.n_reads);
+  } catch (const std::bad_alloc &) {
+    nvk_set_error("out of host memory");
+    return NVK_ERR_NOMEM;
+  }
+  rc = nvk_ws_reserve(ctx, WS_STEPS, (size_t)a.n_reads * sizeof(int32_t));
+  if (rc) return rc;
+  rc = nvk_ws_reserve(ctx, WS_RSTATE, (size_t)a.n_reads * sizeof(int2));
+  if (rc) return rc;
+  hipLaunchKernelGGL(gather_steps_kernel, dim3((unsigned)((a.n_reads + 255) / 256)), dim3(256), 0, ctx->stream,
+                     metas, order, (int)a.n_reads, (int32_t *)ctx->ws[WS_STEPS]);
+  NVK_HIP(hipGetLastError());
+  NVK_HIP(hipMemcpyAsync(steps_sorted.data(), ctx->ws[WS_STEPS], (size_t)a.n_reads * sizeof(int32_t),
+                         hipMemcpyDeviceToHost, ctx->stream));
+  NVK_HIP(hipStreamSynchronize(ctx->stream));
+#endif
+  TimerScope ts_align(ctx, NVK_K_ALIGN);
   for (int k = 0; k < ncls; k++) {
     const int c = cls[k].hi;
     // Rescale period 16, or 8 without transition rows: there the last rows of a sweep run through
@@ -816,35 +1148,17 @@ int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadM
     const int H = c + mel > 0 ? c + mel : 1;
     int SR = 256;
     while (SR < 64 * c + CH) SR <<= 1;
-    size_t lds = (size_t)ETN * 8 + (size_t)SR * 8 + (size_t)H * 64 * 20 + 20 + 16;  // + the zero entry
+    const size_t lds = (size_t)ETN * 8 + (size_t)SR * 8 + (size_t)H * 64 * 20 + 20 + 16;  // + the zero entry
+    const size_t lds_rev = (size_t)ETN * 8 + (size_t)SR * 8 + (size_t)H * 64 * 8 + 8 + 16;  // reverse-only launch
     if (lds > 160 * 1024) return NVK_ERR_UNSUPPORTED;
     int per_cu = (int)((160 * 1024) / lds);
-    if (per_cu > 16) per_cu = 16;
+    if (per_cu > 4 * NVK_LB) per_cu = 4 * NVK_LB;
     if (per_cu < 1) per_cu = 1;
-    int64_t slots = ctx->slots_override > 0 ? ctx->slots_override : (int64_t)ctx->num_cus * per_cu;
-    if (slots > cls[k].reads) slots = cls[k].reads > 0 ? cls[k].reads : 1;
-    const int64_t spill_stride = ((int64_t)max_steps + 2 * PF) * 64;
-    const int64_t L_stride = (int64_t)(max_steps >> rsh) + 4;
+    int per_cu_rev = (int)((160 * 1024) / lds_rev);
+    if (per_cu_rev > 4 * NVK_LB_REV) per_cu_rev = 4 * NVK_LB_REV;
+    if (per_cu_rev < 1) per_cu_rev = 1;
     const int64_t bp_stride = (int64_t)((max_steps + 31) / 32 + 1) * 64;
-    // long reads: the spill of one slot is steps * 512 B (170 MB for a 52 k-sample read with bandwidth
-    // 1000); give the resident waves up to 60 % of what is free on the device (288 GB on an MI355X)
-    // beyond what the workspace already holds, and never less than 48 GB worth
-    int64_t cap = (int64_t)48 << 30;
-    {
-      size_t free_b = 0, total_b = 0;
-      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-        const int64_t avail = (int64_t)((double)(free_b + ctx->ws_bytes[WS_SPILL]) * 0.6);
-        if (avail > cap) cap = avail;
-      }
-    }
-    if (slots * spill_stride * 8 > cap) slots = cap / (spill_stride * 8) > 1 ? cap / (spill_stride * 8) : 1;
-    rc = nvk_ws_reserve(ctx, WS_SPILL, (size_t)slots * spill_stride * 8);
-    if (rc) return rc;
-    rc = nvk_ws_reserve(ctx, WS_STAGE, (size_t)slots * L_stride * 4);
-    if (rc) return rc;
-    rc = nvk_ws_reserve(ctx, WS_BP, (size_t)slots * bp_stride * 4);
-    if (rc) return rc;
-    NVK_HIP(hipMemsetAsync(counter, 0, sizeof(int), ctx->stream));
+    const int64_t cap = nvk_spill_cap(ctx, WS_SPILL);
 
     Align3Args g;
     g.metas = metas;
@@ -852,13 +1166,7 @@ int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadM
     g.revl = (const Lane3 *)ctx->ws[WS_LANE_R];
     g.offs = (const int32_t *)ctx->ws[WS_OFFS];
     g.signal = a.signal;
-    g.spill_v = (double *)ctx->ws[WS_SPILL];
-    g.spill_L = (int32_t *)ctx->ws[WS_STAGE];
-    g.bp = (uint32_t *)ctx->ws[WS_BP];
-    g.spill_stride = spill_stride;
-    g.L_stride = L_stride;
     g.bp_stride = bp_stride;
-    g.n_reads = (int)a.n_reads;
     g.counter = counter;
     g.order = order;
     g.H = H;
@@ -868,17 +1176,77 @@ int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadM
     g.c_cap = cls[k].hi;
     g.flag_above = (k == ncls - 1) ? 1 : 0;
     g.rsh = rsh;
+    g.rstate = (int2 *)ctx->ws[WS_RSTATE];
+    g.read_lo = 0;
     g.n_retry = d_retry;
+    g.ties = (int32_t *)ctx->ws[WS_TIES];
     g.out_events = out_events;
     g.out_status = out_status;
-    void (*kern)(Align3Args) = (rsh == 4) ? kern16 : kernv;
-    if (lds > 64 * 1024)
-      NVK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    {
-      TimerScope ts(ctx, NVK_K_ALIGN);
-      hipLaunchKernelGGL(kern, dim3((unsigned)slots), dim3(64), lds, ctx->stream, g);
+    void (**kern)(Align3Args) = (rsh == 4) ? k16 : kv;
+    for (int ph = 0; ph < 3; ph++)
+      if (kern[ph] && (ph == 1 ? lds_rev : lds) > 64 * 1024)
+        NVK_HIP(hipFuncSetAttribute((const void *)kern[ph], hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(ph == 1 ? lds_rev : lds)));
+#if NVK_TWO_PHASE
+    // chunks of launch positions whose spill fits the cap; a chunk's slots are sized by its longest read
+    int64_t lo = 0;
+    while (lo < a.n_reads) {
+      int64_t hi = lo, mx = 1;
+      while (hi < a.n_reads) {
+        const int64_t m2 = steps_sorted[(size_t)hi] > mx ? steps_sorted[(size_t)hi] : mx;
+        if (hi > lo && (m2 + 2 * PF) * 512 * (hi - lo + 1) > cap) break;
+        mx = m2;
+        ++hi;
+      }
+      const int64_t n_chunk = hi - lo;
+      const int64_t spill_stride = (mx + 2 * PF) * 64;
+      const int64_t L_stride = (mx >> rsh) + 4;
+      rc = nvk_ws_reserve(ctx, WS_SPILL, (size_t)n_chunk * spill_stride * 8);
+      if (rc) return rc;
+      rc = nvk_ws_reserve(ctx, WS_STAGE, (size_t)n_chunk * L_stride * 4);
+      if (rc) return rc;
+      int64_t slots_f = ctx->slots_override > 0 ? ctx->slots_override : (int64_t)ctx->num_cus * per_cu;
+      int64_t slots_r = ctx->slots_override > 0 ? ctx->slots_override : (int64_t)ctx->num_cus * per_cu_rev;
+      if (slots_f > n_chunk) slots_f = n_chunk;
+      if (slots_r > n_chunk) slots_r = n_chunk;
+      rc = nvk_ws_reserve(ctx, WS_BP, (size_t)slots_f * bp_stride * 4);
+      if (rc) return rc;
+      g.spill_v = (double *)ctx->ws[WS_SPILL];
+      g.spill_L = (int32_t *)ctx->ws[WS_STAGE];
+      g.bp = (uint32_t *)ctx->ws[WS_BP];
+      g.spill_stride = spill_stride;
+      g.L_stride = L_stride;
+      g.n_reads = (int)n_chunk;
+      g.read_lo = (int)lo;
+      NVK_HIP(hipMemsetAsync(counter, 0, sizeof(int), ctx->stream));
+      hipLaunchKernelGGL(kern[1], dim3((unsigned)slots_r), dim3(64), lds_rev, ctx->stream, g);
+      NVK_HIP(hipMemsetAsync(counter, 0, sizeof(int), ctx->stream));
+      hipLaunchKernelGGL(kern[2], dim3((unsigned)slots_f), dim3(64), lds, ctx->stream, g);
+      NVK_HIP(hipGetLastError());
+      lo = hi;
     }
+#else
+    int64_t slots = ctx->slots_override > 0 ? ctx->slots_override : (int64_t)ctx->num_cus * per_cu;
+    if (slots > cls[k].reads) slots = cls[k].reads > 0 ? cls[k].reads : 1;
+    const int64_t spill_stride = ((int64_t)max_steps + 2 * PF) * 64;
+    const int64_t L_stride = (int64_t)(max_steps >> rsh) + 4;
+    if (slots * spill_stride * 8 > cap) slots = cap / (spill_stride * 8) > 1 ? cap / (spill_stride * 8) : 1;
+    rc = nvk_ws_reserve(ctx, WS_SPILL, (size_t)slots * spill_stride * 8);
+    if (rc) return rc;
+    rc = nvk_ws_reserve(ctx, WS_STAGE, (size_t)slots * L_stride * 4);
+    if (rc) return rc;
+    rc = nvk_ws_reserve(ctx, WS_BP, (size_t)slots * bp_stride * 4);
+    if (rc) return rc;
+    NVK_HIP(hipMemsetAsync(counter, 0, sizeof(int), ctx->stream));
+    g.spill_v = (double *)ctx->ws[WS_SPILL];
+    g.spill_L = (int32_t *)ctx->ws[WS_STAGE];
+    g.bp = (uint32_t *)ctx->ws[WS_BP];
+    g.spill_stride = spill_stride;
+    g.L_stride = L_stride;
+    g.n_reads = (int)a.n_reads;
+    hipLaunchKernelGGL(kern[0], dim3((unsigned)slots), dim3(64), lds, ctx->stream, g);
     NVK_HIP(hipGetLastError());
+#endif
   }
   NVK_HIP(hipMemcpyAsync(n_retry, d_retry, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   NVK_HIP(hipStreamSynchronize(ctx->stream));

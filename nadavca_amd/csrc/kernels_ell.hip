@@ -79,6 +79,7 @@ struct EllArgs {
   int *counter;
   const int *order;  // reads in the order they are handed out (longest first), or null
   int H, SR;
+  int c_max;  // largest skew the LDS rings of this launch hold: wider reads get NVK_READ_TOO_WIDE
   int wobbling;
   double *out_ll;
   int32_t *out_status;
@@ -499,6 +500,10 @@ __global__ __launch_bounds__(64, 3) void ell_kernel(EllArgs g) {
     }
     const int N = __builtin_amdgcn_readfirstlane(m.N);
     const int c = __builtin_amdgcn_readfirstlane(m.c);
+    if (c > g.c_max) {  // the band does not fit one wave's rings: this read only
+      if (lane == 0) g.out_status[rd] = NVK_READ_TOO_WIDE;
+      continue;
+    }
     const double *sig = g.a.signal + m.sig_off;
     const int32_t *ref = g.a.reference + m.ref_off;
     const int nb = (int)(g.a.cb_off[rd + 1] - g.a.cb_off[rd]);
@@ -803,22 +808,23 @@ int launch_ell(nvk_ctx *ctx, const DeviceModel &dm, const BatchArgs &a, int wobb
     nvk_set_error("k-mer size %d needs %d lanes per hypothesis, compiled limit is %d", dm.k, dm.k + 1, GL);
     return NVK_ERR_UNSUPPORTED;
   }
-  int c = tot.max_c < 1 ? 1 : tot.max_c;
-  int H = c + 1;
-  if (H < 2) H = 2;
-  int SR = 256;
-  while (SR < 64 * c + CH) SR <<= 1;
   // default: the fast variant; NADAVCA_ELL_KERNEL=1 (or a k-mer too long for its lane layout)
   // selects the original formulation
   const char *force = getenv("NADAVCA_ELL_KERNEL");
   const bool fast = !(force && force[0] == '1') && dm.k + 2 <= GL;
-  size_t lds_fast = (size_t)dens::ETN * 8 + (size_t)SR * 8 + (size_t)TABN * sizeof(SweepLane) + (size_t)H * 64 * 24 + 16;
-  size_t lds_exact = (size_t)dens::ETN * 8 + (size_t)SR * 8 + (size_t)TABN * sizeof(FusedParam) + (size_t)H * 64 * 24 + 16;
-  const size_t lds = fast ? lds_fast : lds_exact;
-  if (lds > 160 * 1024) {
-    nvk_set_error("band too wide for one wave per read: skew %d needs %zu bytes of LDS", c, lds);
-    return NVK_ERR_UNSUPPORTED;
-  }
+  // rings sized by the largest skew of the batch that still fits 160 KB of LDS; a read beyond that gets
+  // NVK_READ_TOO_WIDE and the others complete
+  int H = 2, SR = 256;
+  auto lds_for = [&](int cc) {
+    H = cc + 1 < 2 ? 2 : cc + 1;
+    SR = 256;
+    while (SR < 64 * cc + CH) SR <<= 1;
+    return (size_t)dens::ETN * 8 + (size_t)SR * 8 +
+           (size_t)TABN * (fast ? sizeof(SweepLane) : sizeof(FusedParam)) + (size_t)H * 64 * 24 + 16;
+  };
+  int c = tot.max_c < 1 ? 1 : tot.max_c;
+  while (c > 1 && lds_for(c) > 160 * 1024) c--;
+  const size_t lds = lds_for(c);
   int per_cu = (int)((160 * 1024) / lds);
   if (per_cu > 12) per_cu = 12;
   if (per_cu < 1) per_cu = 1;
@@ -833,7 +839,7 @@ int launch_ell(nvk_ctx *ctx, const DeviceModel &dm, const BatchArgs &a, int wobb
   }
   const int64_t half = (int64_t)(tot.max_W > 0 ? tot.max_W : 1) + 64;
   const int64_t stride = 2 * half;
-  const int64_t cap = (int64_t)64 << 30;
+  const int64_t cap = nvk_spill_cap(ctx, WS_SPILL);
   while (slots > 1 && slots * stride * 12 > cap) slots /= 2;
   int rc = nvk_ws_reserve(ctx, WS_SPILL, (size_t)slots * stride * 8);
   if (rc) return rc;
@@ -862,6 +868,7 @@ int launch_ell(nvk_ctx *ctx, const DeviceModel &dm, const BatchArgs &a, int wobb
   }
   g.H = H;
   g.SR = SR;
+  g.c_max = c;
   g.wobbling = wobbling;
   g.out_ll = out_ll;
   g.out_status = out_status;

@@ -34,6 +34,39 @@ __device__ __forceinline__ int64_t kmer_id(const DeviceModel &dm, const int32_t 
   return id;
 }
 
+// What the reference leaves undefined and the C-ABI must refuse (sanitizers): a read whose
+// slices leave the batch's arrays, an anchor outside the band rows, a base code that would index the
+// k-mer table out of range (reference, both contexts).  `nthreads` threads of one block cooperate.
+__device__ __forceinline__ int read_is_bad(const DeviceModel &dm, const BatchArgs &a, int rd, int tid,
+                                           int nthreads) {
+  const int64_t s0 = a.sig_off[rd], s1 = a.sig_off[rd + 1], r0 = a.ref_off[rd], r1 = a.ref_off[rd + 1];
+  const int64_t a0 = a.anc_off[rd], a1 = a.anc_off[rd + 1];
+  const int64_t b0 = a.cb_off[rd], b1 = a.cb_off[rd + 1], c0 = a.ca_off[rd], c1 = a.ca_off[rd + 1];
+  const int64_t N64 = s1 - s0, R64 = r1 - r0;
+  if (s0 < 0 || r0 < 0 || a0 < 0 || b0 < 0 || c0 < 0 || a1 < a0 || b1 < b0 || c1 < c0 ||
+      s1 > a.total_signal || r1 > a.total_ref || a1 > a.total_anchors || b1 - b0 > 0x3fffffff ||
+      c1 - c0 > 0x3fffffff)
+    return 1;
+  if (R64 < 1 || N64 < 1 || N64 > 0x3fffffff || R64 > 0x1fffffff) return 1;
+  const int R = (int)R64, A = (int)(a1 - a0), nb = (int)(b1 - b0), na = (int)(c1 - c0);
+  const int32_t *anc = a.anchors + 2 * a0;
+  const int32_t *ref = a.reference + r0, *cb = a.ctx_before + b0, *ca = a.ctx_after + c0;
+  int bad = 0;
+  // anchors must name an existing band row (reference writes result[reference_index])
+  for (int j = tid; j < A && !bad; j += nthreads) {
+    int si = anc[2 * j], ri = anc[2 * j + 1];
+    if (ri < 0 || ri > R || si < -(1 << 30) || si > (1 << 30)) bad = 1;
+  }
+  const unsigned alpha = (unsigned)dm.alphabet;
+  for (int j = tid; j < R && !bad; j += nthreads)
+    if ((unsigned)ref[j] >= alpha) bad = 1;
+  for (int j = tid; j < nb && !bad; j += nthreads)
+    if ((unsigned)cb[j] >= alpha) bad = 1;
+  for (int j = tid; j < na && !bad; j += nthreads)
+    if ((unsigned)ca[j] >= alpha) bad = 1;
+  return bad;
+}
+
 __device__ __forceinline__ int wave_scan_max(int v, int lane) {
   for (int d = 1; d < 64; d <<= 1) {
     int o = __shfl_up(v, d, 64);
@@ -165,12 +198,7 @@ __global__ __launch_bounds__(PLAN_T) void plan_kernel(DeviceModel dm, BatchArgs 
   m.t_min = 0;
   m.n_steps = 0;
 
-  int bad = (R < 1 || N < 1 || N64 > 0x3fffffff || R64 > 0x1fffffff) ? 1 : 0;
-  // anchors must name an existing band row (reference writes result[reference_index])
-  for (int j = tid; j < A && !bad; j += PLAN_T) {
-    int si = anc[2 * j], ri = anc[2 * j + 1];
-    if (ri < 0 || ri > R || si < -(1 << 30) || si > (1 << 30)) bad = 1;
-  }
+  int bad = read_is_bad(dm, a, rd, tid, PLAN_T);
   bad = __syncthreads_or(bad);
   if (bad) {
     m.status = NVK_READ_BAD_INPUT;
@@ -363,7 +391,8 @@ __global__ __launch_bounds__(PLAN_T) void plan_kernel(DeviceModel dm, BatchArgs 
     m.c = c;
     m.t_min = t_min;
     m.n_steps = t_max - t_min + 1;
-    m.pad = rp[T - 1].hi + off_top - t_min + 1;  // steps under the per-row offsets
+    m.pad = rp[T - 1].hi + off_top - t_min + 1;  // steps under the per-row offsets ...
+    m.pad += m.pad & 1;  // ... made even: kernels_align3 spills two steps per access
     m.cells = cells;
     if (badband) m.status = NVK_READ_BAD_BAND;
     metas[rd] = m;
@@ -422,13 +451,7 @@ __global__ __launch_bounds__(64) void plan_ell_kernel(DeviceModel dm, BatchArgs 
   m.pad = 0;
   m.cells = 0;
 
-  int bad = (R < 1 || N < 1 || N64 > 0x3fffffff || R64 > 0x1fffffff) ? 1 : 0;
-  for (int j = lane; j < A && !bad; j += 64) {
-    int si = anc[2 * j], ri = anc[2 * j + 1];
-    if (ri < 0 || ri > R || si < -(1 << 30) || si > (1 << 30)) bad = 1;
-  }
-  for (int j = lane; j < R && !bad; j += 64)
-    if (ref[j] < 0 || ref[j] >= dm.alphabet) bad = 1;
+  int bad = read_is_bad(dm, a, rd, lane, 64);
   bad = __any(bad);
   if (bad) {
     m.status = NVK_READ_BAD_INPUT;
@@ -525,167 +548,6 @@ __global__ __launch_bounds__(64) void plan_ell_kernel(DeviceModel dm, BatchArgs 
 }
 
 
-// ---------------------------------------------------------------------------------------------
-// planner for refine_alignment v2 (fused lanes, see kernels_align4.hip): lane tables of the
-// prefix sweep and of the mirrored suffix sweep, common skew c.
-// Row layout restated from dtw.cpp:144-180: with transitions the rows are
-//   0 (start, band 0), then per base j: 2j+1 (emit k-mer j, band j+1), 2j+2 (transition j->j+1,
-//   band j+1; absent after the last base); without transitions row j+1 = emit k-mer j.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void plan_align2_kernel(DeviceModel dm, BatchArgs a,
-                                                         int transitions, int c_cap,
-                                                         Align2Plan pl, unsigned long long *bandtmp,
-                                                         PlanTotals *totals) {
-  const int rd = blockIdx.x;
-  const int lane = threadIdx.x;
-  if (rd >= a.n_reads) return;
-  const int64_t s0 = a.sig_off[rd], r0 = a.ref_off[rd], a0 = a.anc_off[rd];
-  const int64_t N64 = a.sig_off[rd + 1] - s0;
-  const int64_t R64 = a.ref_off[rd + 1] - r0;
-  const int A = (int)(a.anc_off[rd + 1] - a0);
-  const int nb = (int)(a.cb_off[rd + 1] - a.cb_off[rd]);
-  const int na = (int)(a.ca_off[rd + 1] - a.ca_off[rd]);
-  const int32_t *ref = a.reference + r0;
-  const int32_t *cb = a.ctx_before + a.cb_off[rd];
-  const int32_t *ca = a.ctx_after + a.ca_off[rd];
-  const int32_t *anc = a.anchors + 2 * a0;
-  const int N = (int)N64, R = (int)R64, mel = a.mel;
-
-  ReadMeta m;
-  m.sig_off = s0;
-  m.ref_off = r0;
-  m.row_off = r0 + rd;  // R+1 lanes per read
-  m.N = N;
-  m.R = R;
-  m.T = transitions ? 2 * R : R + 1;
-  m.c = 1;
-  m.t_min = 0;
-  m.n_steps = 0;
-  m.status = NVK_READ_OK;
-  m.pad = 0;
-  m.cells = 0;
-  int bad = (R < 1 || N < 1 || N64 > 0x3fffffff || R64 > 0x1fffffff) ? 1 : 0;
-  for (int j = lane; j < A && !bad; j += 64) {
-    int si = anc[2 * j], ri = anc[2 * j + 1];
-    if (ri < 0 || ri > R || si < -(1 << 30) || si > (1 << 30)) bad = 1;
-  }
-  bad = __any(bad);
-  if (bad) {
-    m.status = NVK_READ_BAD_INPUT;
-    if (lane == 0) pl.metas[rd] = m;
-    return;
-  }
-  unsigned long long *tbs = bandtmp + 2 * (r0 + rd);
-  unsigned long long *tbe = tbs + (R + 1);
-  plan_bands(anc, A, R, N, a.bandwidth, tbs, tbe, lane);
-
-  AlignLane *fw = pl.fwd + m.row_off, *rv = pl.rev + m.row_off;
-  int badband = 0;
-  long long cells = 0;
-  const int pre = mel > 1 ? mel - 1 : 0;  // pre-roll so that the emission product is complete
-  for (int f = lane; f <= R; f += 64) {
-    const int bsf = (int)(unsigned int)tbs[f], bef = (int)(unsigned int)tbe[f];
-    if (bef < bsf) badband = 1;
-    // algorithmic cell count: sum of the band widths of all reference rows
-    {
-      long long w = (long long)(bef - bsf + 1);
-      int rows_on_band = transitions ? ((f == 0 || f == R) ? 1 : 2) : 1;
-      cells += w * rows_on_band;
-    }
-    // ---- prefix sweep, lane f
-    AlignLane L;
-    L.mean = L.ac = L.mc = 0.0;
-    L.pad = 0;
-    int lo_f, lo_r;
-    L.bs = bsf;
-    L.be = bef;
-    if (f == 0) {
-      L.flags = 2 | 4;
-      L.pbs = bsf;
-      L.pbe = bef;
-      lo_f = bsf;
-    } else {
-      const int j = f - 1;
-      int64_t id = kmer_id(dm, ref, R, cb, nb, ca, na, j);
-      L.mean = dm.mean[id];
-      L.ac = dm.ac[id];
-      L.mc = dm.mc[id];
-      L.pbs = (int)(unsigned int)tbs[j];
-      L.pbe = (int)(unsigned int)tbe[j];
-      L.flags = 1;
-      if (transitions && j + 1 < R) {
-        L.flags |= 2;
-        double m2 = dm.mean[kmer_id(dm, ref, R, cb, nb, ca, na, j + 1)];
-        if (L.mean == m2) L.flags |= 8;
-      }
-      lo_f = min(bsf, L.pbs + mel) - pre;
-    }
-    fw[f] = L;
-    // ---- mirrored suffix sweep, lane f: start row on band R (f = 0), else emit k-mer R-f from
-    // band R-f+1 into band R-f, then the transition (R-f-1 -> R-f) on band R-f
-    AlignLane M;
-    M.mean = M.ac = M.mc = 0.0;
-    M.pad = 0;
-    const int bi = R - f;  // band index of this lane's rows
-    M.bs = N - (int)(unsigned int)tbe[bi];
-    M.be = N - (int)(unsigned int)tbs[bi];
-    if (f == 0) {
-      M.flags = 2 | 4;
-      M.pbs = M.bs;
-      M.pbe = M.be;
-      lo_r = M.bs;
-    } else {
-      const int kj = R - f;  // k-mer of the emitting step
-      int64_t id = kmer_id(dm, ref, R, cb, nb, ca, na, kj);
-      M.mean = dm.mean[id];
-      M.ac = dm.ac[id];
-      M.mc = dm.mc[id];
-      M.pbs = N - (int)(unsigned int)tbe[bi + 1];
-      M.pbe = N - (int)(unsigned int)tbs[bi + 1];
-      M.flags = 1;
-      if (transitions && kj >= 1) {
-        M.flags |= 2;
-        double m1 = dm.mean[kmer_id(dm, ref, R, cb, nb, ca, na, kj - 1)];
-        if (m1 == M.mean) M.flags |= 8;
-      }
-      lo_r = min(M.bs, M.pbs + mel) - pre;
-    }
-    rv[f] = M;
-    // lane occupancy starts ride in the pad words
-    fw[f].pad = lo_f;
-    rv[f].pad = lo_r;
-  }
-  badband = __any(badband);
-  cells = wave_sum(cells);
-  __syncthreads();
-  // common skew: a lane (f mod 32) must be free before lane f + 32 starts, in both sweeps
-  int cneed = max(1, mel - 1);
-  for (int f = 32 + lane; f <= R; f += 64) {
-    int d = max(fw[f - 32].be - fw[f].pad, rv[f - 32].be - rv[f].pad);
-    if (d >= 0) cneed = max(cneed, d / 32 + 1);
-  }
-  int c = wave_max(cneed);
-  if (lane == 0) {
-    const int tmin_f = fw[0].pad, tmax_f = fw[R].be + c * R;
-    const int tmin_r = rv[0].pad, tmax_r = rv[R].be + c * R;
-    m.c = c;
-    m.t_min = tmin_f;
-    m.n_steps = max(tmax_f - tmin_f, tmax_r - tmin_r) + 1;
-    m.pad = tmin_r;  // first step of the mirrored sweep
-    m.cells = cells;
-    if (badband) m.status = NVK_READ_BAD_BAND;
-    pl.metas[rd] = m;
-    if (!badband) {
-      atomicMax(&totals->max_steps, m.n_steps);
-      atomicMax(&totals->max_c, c);
-      if (c > c_cap) atomicAdd(&totals->n_wide, 1);
-      atomicMax(&totals->max_T, R + 1);
-      atomicAdd(&totals->cells, (unsigned long long)cells);
-      atomicAdd(&totals->steps, (unsigned long long)m.n_steps);
-    }
-  }
-}
-
 __global__ void expected_kernel(DeviceModel dm, int64_t n_reads, int64_t total_ref,
                                 const int32_t *reference, const int64_t *ref_off,
                                 const int32_t *cbs, const int64_t *cb_off, const int32_t *cas,
@@ -703,8 +565,13 @@ __global__ void expected_kernel(DeviceModel dm, int64_t n_reads, int64_t total_r
   int nb = (int)(cb_off[rd + 1] - cb_off[rd]);
   int na = (int)(ca_off[rd + 1] - ca_off[rd]);
   int pos = (int)(g - ref_off[rd]);
-  int64_t id = kmer_id(dm, reference + ref_off[rd], R, cbs + cb_off[rd], nb, cas + ca_off[rd], na, pos);
-  out[g] = dm.mean[id];
+  // a base code outside 0..alphabet-1 anywhere in the k-mer's window: no table entry exists (the reference
+  // indexes out of bounds there, kmer_model.cpp:22-30); the level is reported as NaN
+  const int32_t *ref = reference + ref_off[rd], *cb = cbs + cb_off[rd], *ca = cas + ca_off[rd];
+  bool ok = true;
+  for (int j = pos - dm.central; j < pos - dm.central + dm.k; j++)
+    ok = ok && ((unsigned)seq_at(ref, R, cb, nb, ca, na, j) < (unsigned)dm.alphabet);
+  out[g] = ok ? dm.mean[kmer_id(dm, ref, R, cb, nb, ca, na, pos)] : (double)NAN;
 }
 
 
@@ -742,7 +609,23 @@ __global__ void order_fill_kernel(const ReadMeta *metas, int n, int max_steps, i
   }
 }
 
+__global__ void count_flags_kernel(const int32_t *flags, int64_t n, int32_t *out) {
+  int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int v = (g < n && flags[g] != 0) ? 1 : 0;
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  if ((threadIdx.x & 63) == 0 && v) atomicAdd(out, v);
+}
+
 }  // namespace
+
+int launch_count_flags(nvk_ctx *ctx, const int32_t *flags, int64_t n, int32_t *out_count) {
+  NVK_HIP(hipMemsetAsync(out_count, 0, sizeof(int32_t), ctx->stream));
+  if (n <= 0) return NVK_OK;
+  hipLaunchKernelGGL(count_flags_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, flags, n,
+                     out_count);
+  NVK_HIP(hipGetLastError());
+  return NVK_OK;
+}
 
 // order[0..n) = read indices, longest (by step count) first; `order` lives in ctx->ws[WS_ORDER]
 int launch_order(nvk_ctx *ctx, const ReadMeta *metas, int64_t n_reads, int max_steps, int **order) {
@@ -787,20 +670,6 @@ int launch_plan_ell(nvk_ctx *ctx, const DeviceModel &dm, const BatchArgs &a, int
     TimerScope ts(ctx, NVK_K_PLAN);
     hipLaunchKernelGGL(plan_ell_kernel, dim3((unsigned)a.n_reads), dim3(64), 0, ctx->stream, dm, a,
                        wobbling, pl, bandtmp, totals);
-  }
-  NVK_HIP(hipGetLastError());
-  return NVK_OK;
-}
-
-int launch_plan_align2(nvk_ctx *ctx, const DeviceModel &dm, const BatchArgs &a, int transitions,
-                       int c_cap, const Align2Plan &pl, unsigned long long *bandtmp,
-                       PlanTotals *totals) {
-  NVK_HIP(hipMemsetAsync(totals, 0, sizeof(PlanTotals), ctx->stream));
-  if (a.n_reads == 0) return NVK_OK;
-  {
-    TimerScope ts(ctx, NVK_K_PLAN);
-    hipLaunchKernelGGL(plan_align2_kernel, dim3((unsigned)a.n_reads), dim3(64), 0, ctx->stream, dm,
-                       a, transitions, c_cap, pl, bandtmp, totals);
   }
   NVK_HIP(hipGetLastError());
   return NVK_OK;

@@ -35,23 +35,6 @@ struct __attribute__((aligned(16))) FusedParam {
 };
 static_assert(sizeof(FusedParam) == 80, "FusedParam layout");
 
-// refine_alignment v2: one entry per lane f = 0..R of a sweep (f = 0 is the all-ones start row,
-// f >= 1 is base f-1).  A lane owns up to two consecutive reference rows on ONE band:
-//   slot A  the emitting row (Gaussian of the base's k-mer, min event length mel), fed by the
-//           previous lane's last row through band [pbs, pbe];
-//   slot B  the transition row that follows it (constant density et, min event length 0,
-//           kmer_model.cpp:64-94), or the all-ones start row for f = 0.
-// Coordinates are those of the sweep (the suffix sweep runs on mirrored coordinates i' = N - i).
-struct __attribute__((aligned(16))) AlignLane {
-  double mean, ac, mc;  // slot A density
-  int32_t pbs, pbe;     // band of the predecessor row
-  int32_t bs, be;       // band of this lane's rows
-  int32_t flags;        // 1 has slot A, 2 has slot B, 4 slot B is the all-ones start row,
-                        // 8 slot B's transition is impossible (equal k-mer means -> density 0)
-  int32_t pad;          // lo: first cell the lane computes (band start minus warm-up / pre-roll)
-};
-static_assert(sizeof(AlignLane) == 48, "AlignLane layout");
-
 struct ReadMeta {
   int64_t sig_off;   // first sample of the read's signal slice
   int64_t row_off;   // first RowParam of the read
@@ -63,8 +46,7 @@ struct ReadMeta {
   int32_t t_min;     // first step
   int32_t n_steps;   // number of steps
   int32_t status;    // NVK_READ_*
-  int32_t pad;       // align planner: number of steps under the per-row offsets RowParam::off;
-                     // paired planner: first step of the mirrored sweep
+  int32_t pad;       // align planner: number of steps under the per-row offsets RowParam::off
   int64_t cells;     // sum of band widths (algorithmic cell count)
 };
 
@@ -87,12 +69,12 @@ struct DeviceModel {
 
 // ----- host-side objects ------------------------------------------------------------------
 enum { WS_META = 0, WS_ROWS = 1, WS_BANDTMP = 2, WS_SPILL = 3, WS_BP = 4, WS_MISC = 5, WS_ROWS2 = 6, WS_STAGE = 7,
-       WS_SPILL_B = 8, WS_STAGE_B = 9, WS_BP_B = 10, WS_LANE_F = 11, WS_LANE_R = 12, WS_ORDER = 13, WS_OFFS = 14, WS_COUNT = 15 };
+       WS_SPILL_B = 8, WS_STAGE_B = 9, WS_BP_B = 10, WS_LANE_F = 11, WS_LANE_R = 12, WS_ORDER = 13, WS_OFFS = 14, WS_TIES = 15, WS_RSTATE = 16, WS_STEPS = 17, WS_COUNT = 18 };
 
 struct nvk_ctx {
   int device;
   hipStream_t stream;
-  hipStream_t stream2;   // side stream: the wide-skew class of the paired align kernel runs here
+  hipStream_t stream2;   // side stream: the wide-skew class of the exact align kernel runs here
   hipEvent_t ev_fork, ev_join;
   int slots_override;
   int num_cus;
@@ -107,6 +89,9 @@ struct nvk_ctx {
   // stats of the last batch
   int64_t last_cells, last_steps, last_spill_bytes;
   int64_t last_retries;  // reads of the last refine batch redone by the exact kernel
+  int64_t last_ties;     // reads of the last refine batch with a path decision inside the tolerance band
+  int64_t ties_n;        // number of reads ws[WS_TIES] describes
+  int64_t ws_limit;      // nvk_ctx_set_workspace_limit: cap on the sweep kernels' spill workspace (0 = default)
 };
 
 struct nvk_model {
@@ -171,20 +156,13 @@ int launch_plan_ell(nvk_ctx *ctx, const DeviceModel &dm, const BatchArgs &a, int
                     const EllPlan &pl, unsigned long long *bandtmp, PlanTotals *totals);
 int launch_ell(nvk_ctx *ctx, const DeviceModel &dm, const BatchArgs &a, int wobbling,
                const EllPlan &pl, const PlanTotals &tot, double *out_ll, int32_t *out_status);
-struct Align2Plan {
-  ReadMeta *metas;
-  AlignLane *fwd;  // [total_ref + n] lanes of the prefix sweep
-  AlignLane *rev;  // [total_ref + n] lanes of the mirrored suffix sweep
-};
+// *out_count = number of nonzero entries of flags[0..n)
+int launch_count_flags(nvk_ctx *ctx, const int32_t *flags, int64_t n, int32_t *out_count);
+// bytes the resident waves' spill may take: the ctx limit if set, else a default share of the free memory
+int64_t nvk_spill_cap(nvk_ctx *ctx, int which_ws);
 // internal per-read status of the scaled-double kernel: the exact kernel must redo this read
 constexpr int NVK_READ_RETRY_INTERNAL = 2;
 constexpr int ALIGN1_C_CAP = 3;  // skew served by the main launch of the one-read-per-wave kernel
-constexpr int ALIGN2_C_CAP = 3;  // skew served by the main launch of the paired kernel
-int launch_align4(nvk_ctx *ctx, const BatchArgs &a, int transitions, const Align2Plan &pl,
-                  const PlanTotals &tot, int32_t *out_events, int32_t *out_status, int *n_retry);
-int launch_plan_align2(nvk_ctx *ctx, const DeviceModel &dm, const BatchArgs &a, int transitions,
-                       int c_cap, const Align2Plan &pl, unsigned long long *bandtmp,
-                       PlanTotals *totals);
 // only_retry != 0: serve only the reads whose out_status is NVK_READ_RETRY_INTERNAL
 int launch_align_retry(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadMeta *metas,
                        const RowParam *rows, const PlanTotals &tot, int32_t *out_events,

@@ -112,6 +112,13 @@ __device__ __forceinline__ bool gt_tol(X a, X b) {
   return diff > thr;
 }
 
+// the tie flag of the parity contract (include/nadavca_hip.h): a and b are closer than 2^-24 relative
+// (never for a zero a, nor against a zero b)
+__device__ __forceinline__ bool near_tol(X a, X b) {
+  double am = ldexp(a.m, a.e - b.e);
+  return fabs(am - b.m) < am * 0x1.0p-24 && b.m != 0.0;
+}
+
 // c ? a : b.  (gfx950 note, tools/ubench_valu.hip: a v_cndmask_b32_e32 that re-reads an unchanged
 // vcc costs ~20 cycles, and hipcc lowers 64-bit selects to such pairs; forcing the e64/SGPR-mask
 // form through inline asm was measured and bought nothing at this kernel's occupancy, so the

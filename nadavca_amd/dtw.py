@@ -19,7 +19,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import READ_OK, READ_NO_PATH, READ_BAD_INPUT, READ_BAD_BAND  # noqa: F401
+from ._lib import READ_OK, READ_NO_PATH, READ_BAD_INPUT, READ_BAD_BAND, READ_TOO_WIDE  # noqa: F401
 
 
 def _ptr(a):
@@ -129,6 +129,10 @@ class KmerModel:
         ca = [_i32(a) for _, _, a in items]
         cat = lambda xs: np.concatenate(xs) if xs else np.zeros(0, np.int32)
         r, b, a = cat(ref), cat(cb), cat(ca)
+        for name, v in (('reference', r), ('context_before', b), ('context_after', a)):
+            if v.size and (int(v.min()) < 0 or int(v.max()) >= self.alphabet_size):
+                raise ValueError('get_expected_signal: %s holds a base code outside 0..%d'
+                                 % (name, self.alphabet_size - 1))
         ro, bo, ao = _offsets([x.size for x in ref]), _offsets([x.size for x in cb]), _offsets([x.size for x in ca])
         out = np.zeros(r.size, dtype=np.float64)
         _lib.check(self._lib.nvk_expected_signal_batch(self.handle, len(items), _ptr(r), _ptr(ro), _ptr(b),
@@ -157,22 +161,35 @@ class KmerModel:
 # ------------------------------------------------------------------------------------------------
 # batched operators
 # ------------------------------------------------------------------------------------------------
-def refine_alignment_flat(batch, bandwidth, min_event_length, kmer_model, model_transitions):
-    """-> (events int32 (sum R, 2), status int32 (n,)) for a FlatBatch."""
+def _raise_on_status(what, status):
+    """Per-read failures as exceptions (the per-read operators of the reference raise too): invalid input
+    -> ValueError; a band wider than the compiled kernels serve -> NadavcaHipError."""
+    bad = np.nonzero((status < 0) & (status != READ_TOO_WIDE))[0]
+    if bad.size:
+        raise ValueError('%s: invalid input for read(s) %s (status %s)'
+                         % (what, bad[:8].tolist(), status[bad[:8]].tolist()))
+    wide = np.nonzero(status == READ_TOO_WIDE)[0]
+    if wide.size:
+        raise _lib.NadavcaHipError('%s: the band of read(s) %s is wider than the compiled kernels serve '
+                                   '(INTEGRATION.md, limits)' % (what, wide[:8].tolist()))
+
+
+def refine_alignment_flat(batch, bandwidth, min_event_length, kmer_model, model_transitions, on_error='raise'):
+    """-> (events int32 (sum R, 2), status int32 (n,)) for a FlatBatch.  on_error='status': per-read
+    failures (status < 0) are left to the caller instead of raised."""
     lib = _lib.load()
     events = np.zeros((int(batch.ref_off[-1]), 2), dtype=np.int32)
     status = np.zeros(batch.n, dtype=np.int32)
     _lib.check(lib.nvk_refine_alignment_batch(kmer_model.handle, batch.n, *batch.pointers(), int(bandwidth),
                                               int(min_event_length), int(bool(model_transitions)),
                                               _ptr(events), _ptr(status)), 'nvk_refine_alignment_batch')
-    bad = np.nonzero(status < 0)[0]
-    if bad.size:
-        raise ValueError('refine_alignment: invalid input for read(s) %s (status %s)'
-                         % (bad[:8].tolist(), status[bad[:8]].tolist()))
+    if on_error == 'raise':
+        _raise_on_status('refine_alignment', status)
     return events, status
 
 
-def estimate_log_likelihoods_flat(batch, bandwidth, min_event_length, kmer_model, model_wobbling):
+def estimate_log_likelihoods_flat(batch, bandwidth, min_event_length, kmer_model, model_wobbling,
+                                  on_error='raise'):
     """-> (ll f64 (sum R, alphabet), status int32 (n,)) for a FlatBatch."""
     lib = _lib.load()
     alpha = kmer_model.alphabet_size
@@ -182,25 +199,26 @@ def estimate_log_likelihoods_flat(batch, bandwidth, min_event_length, kmer_model
                                                       int(bandwidth), int(min_event_length),
                                                       int(bool(model_wobbling)), _ptr(ll), _ptr(status)),
                'nvk_estimate_log_likelihoods_batch')
-    bad = np.nonzero(status < 0)[0]
-    if bad.size:
-        raise ValueError('estimate_log_likelihoods: invalid input for read(s) %s (status %s)'
-                         % (bad[:8].tolist(), status[bad[:8]].tolist()))
+    if on_error == 'raise':
+        _raise_on_status('estimate_log_likelihoods', status)
     return ll, status
 
 
-def refine_alignment_batch(reads, bandwidth, min_event_length, kmer_model, model_transitions):
+def refine_alignment_batch(reads, bandwidth, min_event_length, kmer_model, model_transitions,
+                           on_error='raise', return_status=False):
     """reads: list of (signal, reference, context_before, context_after, approximate_alignment).
-    -> list of (R, 2) int arrays; an empty (0, 2) array where the band holds no valid path."""
+    -> list of (R, 2) int arrays; an empty (0, 2) array where the band holds no valid path (and, with
+    on_error='status', where the read was refused: return_status=True also returns the status array)."""
     batch = reads if isinstance(reads, FlatBatch) else FlatBatch(reads)
-    events, status = refine_alignment_flat(batch, bandwidth, min_event_length, kmer_model, model_transitions)
+    events, status = refine_alignment_flat(batch, bandwidth, min_event_length, kmer_model, model_transitions,
+                                           on_error=on_error)
     out = []
     for j in range(batch.n):
         if status[j] == READ_OK:
             out.append(events[batch.ref_off[j]:batch.ref_off[j + 1]])
         else:
             out.append(np.zeros((0, 2), dtype=np.int32))
-    return out
+    return (out, status) if return_status else out
 
 
 def estimate_log_likelihoods_batch(reads, bandwidth, min_event_length, kmer_model, model_wobbling):

@@ -42,8 +42,23 @@ def kmer_ids(seq_ext, offset, length, k, central, alphabet=4):
     return ids
 
 
+def homopolymer_rich(rng, n, alphabet, mean_run=3.0, long_run_share=0.1, long_run=(7, 12)):
+    """A base sequence made of runs: geometric run lengths (mean ``mean_run``), a share of them long —
+    real genomes hold many runs of k+1 equal bases, iid sequences almost none (P = 4^-k per position)."""
+    out = np.empty(0, dtype=np.int64)
+    prev = -1
+    while out.size < n:
+        b = int(rng.integers(0, alphabet - 1))
+        b += (b >= prev) if prev >= 0 else 0          # a new run never repeats the previous base
+        run = int(rng.integers(long_run[0], long_run[1] + 1)) if rng.random() < long_run_share \
+            else int(rng.geometric(1.0 / mean_run))
+        out = np.concatenate([out, np.full(run, b, dtype=np.int64)])
+        prev = b
+    return out[:n]
+
+
 def make_dp_case(rng, model, R=400, bandwidth=150, dwell=(3, 17), noise=0.35,
-                 anchor_density=0.75, jitter=20, with_context=True, trim=3, pad_bases=None):
+                 anchor_density=0.75, jitter=20, with_context=True, trim=3, pad_bases=None, bases=None):
     """One DP problem in the argument shape of ``dtw.refine_alignment`` /
     ``dtw.estimate_log_likelihoods``.  Returns a dict with signal (f64), reference,
     context_before, context_after (int32), approximate_alignment (int32 (A,2)),
@@ -52,7 +67,9 @@ def make_dp_case(rng, model, R=400, bandwidth=150, dwell=(3, 17), noise=0.35,
     lo, hi = dwell
     if pad_bases is None:
         pad_bases = int(np.ceil(bandwidth / ((lo + hi) / 2.0))) + 6
-    full = rng.integers(0, alphabet, R + 2 * pad_bases)
+    # `bases`: callable (rng, n, alphabet) -> base codes, default iid uniform
+    full = rng.integers(0, alphabet, R + 2 * pad_bases) if bases is None else \
+        np.asarray(bases(rng, R + 2 * pad_bases, alphabet), dtype=np.int64)
     ids = kmer_ids(full, 0, full.size, k, central, alphabet)
     dw = rng.integers(lo, hi + 1, full.size)
     starts = np.concatenate([[0], np.cumsum(dw)])

@@ -124,12 +124,11 @@ def test_invalid_input_raises(dtw):
         dtw.refine_alignment(np.zeros(50), [0, 1, 2], [], [], [[5, 7]], 10, 2, m, True)  # anchor outside ref
 
 
-@pytest.mark.parametrize('variant', ['1', '2'])
+@pytest.mark.parametrize('variant', ['1'])
 def test_kernel_variants_match(golden_config, variant):
     """NADAVCA_ALIGN_KERNEL=1 (the exact scaled-number kernel that also serves as the default kernel's
-    fallback) and =2 (fused lanes, two reads per wave) are further implementations of the same
-    operator: run each in a child process (the variant is read from the environment at call time) on
-    the config-sized fixtures and on seeded reads."""
+    fallback) is a second implementation of the same operator: run it in a child process (the variant is
+    read from the environment at call time) on the config-sized fixtures and on seeded reads."""
     import os
     import subprocess
     import sys
@@ -163,8 +162,8 @@ for mel in (0, 1, 2, 3, 4):
             for x, ev in zip(cases, got):
                 exp = o.refine_alignment(x["signal"], x["reference"], x["context_before"], x["context_after"], x["approximate_alignment"], bw, mel, mo, tr)
                 assert ev.shape == exp.shape and np.array_equal(ev, exp), ("oracle mismatch", mel, bw, tr)
-print("PAIRED-OK")
+print("VARIANT-OK")
 ''' % (ROOT, ROOT)
     env = dict(os.environ, NADAVCA_ALIGN_KERNEL=variant)
     p = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
-    assert p.returncode == 0 and 'PAIRED-OK' in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+    assert p.returncode == 0 and 'VARIANT-OK' in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]

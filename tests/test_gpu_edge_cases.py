@@ -183,3 +183,79 @@ def test_ell_long_read_wide_band(dtw, oracle_port):
         assert np.array_equal(np.isneginf(got), np.isneginf(exp)) and not np.any(np.isnan(got))
         fin = np.isfinite(exp)
         assert np.allclose(got[fin], exp[fin], rtol=1e-9, atol=1e-9)
+
+
+def test_base_codes_outside_the_alphabet_are_refused(dtw, oracle_port):
+    """A base code < 0 or >= alphabet in the reference or in either context would index the k-mer table
+    out of bounds (the reference does exactly that, kmer_model.cpp:22-30): the C-ABI refuses the read
+    (NVK_READ_BAD_INPUT -> ValueError), the other reads of the batch are served, and get_expected_signal
+    raises."""
+    from nadavca_amd import synthetic
+    model = synthetic.synth_model_arrays(9, k=4, central=1)
+    m = dtw.KmerModel(*model)
+    mo = oracle_port.KmerModel(*model)
+    rng = np.random.default_rng(907)
+    good = synthetic.make_dp_case(rng, model, R=25, bandwidth=15, dwell=(3, 6), jitter=2)
+    tup = lambda c: (c['signal'], c['reference'], c['context_before'], c['context_after'], c['approximate_alignment'])
+    for field, pos, code in (('reference', 7, 4), ('reference', 0, -1), ('context_before', 0, 4),
+                             ('context_after', 1, -1), ('context_after', 0, 1 << 30)):
+        bad = dict(good)
+        v = np.array(good[field]).copy()
+        v[pos] = code
+        bad[field] = v
+        for tr in (True, False):
+            with pytest.raises(ValueError):
+                dtw.refine_alignment(*tup(bad), 15, 2, m, tr)
+            out, st = dtw.refine_alignment_batch([tup(good), tup(bad), tup(good)], 15, 2, m, tr,
+                                                 on_error='status', return_status=True)
+            assert st.tolist() == [0, dtw.READ_BAD_INPUT, 0] and len(out[1]) == 0
+            exp = oracle_port.refine_alignment(*tup(good), 15, 2, mo, tr)
+            assert np.array_equal(out[0], exp) and np.array_equal(out[2], exp)
+        with pytest.raises(ValueError):
+            dtw.estimate_log_likelihoods(*tup(bad), 15, 2, m, True)
+        with pytest.raises(ValueError):
+            m.get_expected_signal(bad['reference'], bad['context_before'], bad['context_after'])
+
+
+def test_one_over_wide_read_does_not_fail_the_batch(dtw, oracle_port):
+    """A config-2-sized read WITHOUT anchors has the whole matrix as its band (~4 300 cells per row, wavefront
+    skew ~ 68): more than one wave's LDS rings hold.  It gets its own status (NVK_READ_TOO_WIDE) and the
+    normal reads of the same batch come out as if it were not there."""
+    from nadavca_amd import synthetic, _lib
+    model = synthetic.load_model_arrays()
+    m = dtw.KmerModel(*model)
+    mo = oracle_port.KmerModel(*model)
+    cases = [synthetic.make_dp_case(np.random.default_rng([908, i]), model, R=400, bandwidth=150) for i in range(5)]
+    tup = lambda c: (c['signal'], c['reference'], c['context_before'], c['context_after'], c['approximate_alignment'])
+    wide = dict(cases[2], approximate_alignment=np.zeros((0, 2), dtype=np.int32))
+    reads = [tup(cases[0]), tup(cases[1]), tup(wide), tup(cases[3]), tup(cases[4])]
+    for tr in (True, False):
+        out, st = dtw.refine_alignment_batch(reads, 150, 2, m, tr, on_error='status', return_status=True)
+        assert st.tolist() == [0, 0, dtw.READ_TOO_WIDE, 0, 0]
+        for i in (0, 1, 3, 4):
+            exp = oracle_port.refine_alignment(*tup(cases[i]), 150, 2, mo, tr)
+            assert np.array_equal(out[i], exp)
+        with pytest.raises(_lib.NadavcaHipError):
+            dtw.refine_alignment_batch(reads, 150, 2, m, tr)
+    ll, st = dtw.estimate_log_likelihoods_flat(dtw.FlatBatch(reads), 150, 2, m, True, on_error='status')
+    assert st.tolist() == [0, 0, dtw.READ_TOO_WIDE, 0, 0]
+    exp = oracle_port.estimate_log_likelihoods(*tup(cases[4]), 150, 2, mo, True)
+    off = np.concatenate([[0], np.cumsum([len(c['reference']) for c in (cases[0], cases[1], wide, cases[3], cases[4])])])
+    assert np.allclose(ll[off[4]:off[5]], exp, rtol=1e-9, atol=1e-9)
+
+
+def test_workspace_limit_changes_nothing_but_the_footprint(dtw, oracle_port):
+    """nvk_ctx_set_workspace_limit caps the spill the resident waves may take; fewer reads are in flight,
+    results are the same."""
+    from nadavca_amd import synthetic, _lib
+    model = synthetic.load_model_arrays()
+    ctx = _lib.Context(0)
+    m = dtw.KmerModel(*model, context=ctx)
+    batch = synthetic.make_batch(300, model, seed=909, R=200, R_spread=20, bandwidth=100)
+    reads = [(c['signal'], c['reference'], c['context_before'], c['context_after'], c['approximate_alignment'])
+             for c in batch.cases]
+    free = dtw.refine_alignment_batch(reads, 100, 2, m, True)
+    ctx.set_workspace_limit(32 << 20)   # 32 MB: a couple of dozen resident waves
+    capped = dtw.refine_alignment_batch(reads, 100, 2, m, True)
+    ctx.set_workspace_limit(0)
+    assert all(np.array_equal(a, b) for a, b in zip(free, capped))
