@@ -2,18 +2,30 @@
 """Headline benchmark: reads/sec of the signal-to-reference alignment path on MI355X.
 
 Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N>1 launched through
-torch.distributed.run with one rank per GPU.  A *step* is one pass of the hot path
-(``refine_alignment``, transitions on — the ``align_signal`` path) over one batch of synthetic
-reads that is already resident in HBM.  At N=1 the batch is BASELINE.json configs[1]:
-10 000 reads, ~4 000 samples each, bandwidth 150, packaged 6-mer model.  Reads shard
-embarrassingly: every rank aligns its own batch (weak scaling, no data-path collective).
+torch.distributed.run with one rank per GPU.  A *step* is one pass of the hot path over one batch of
+synthetic reads that is already resident in HBM.  Workloads (``--workload``):
+
+  cfg2_align (default)  BASELINE.json configs[1]: ``refine_alignment`` (transitions on — the ``align_signal``
+                        path) over 10 000 reads, ~4 300 samples each, bandwidth 150, packaged 6-mer model.
+                        Reads shard embarrassingly: every rank aligns its own batch (weak scaling, no
+                        data-path collective).
+  cfg3_snps             configs[2]: ``estimate_log_likelihoods`` (wobbling on) over the same shape.
+  cfg4_consensus        configs[3]: the ``estimate_snps(independent=False)`` data path per rank —
+                        log-likelihoods -> normalise / strand-flip / scatter-add into the per-position sums
+                        (device) -> ONE reduce(sum) of the packed [L, 5] f64 buffer over all ranks (RCCL over
+                        xGMI when N > 1) -> posterior on the root.  Reads per rank fixed (weak scaling).
+  cfg5_long             configs[4] shape on one GPU: ~50 000-sample reads, bandwidth 1000.
+  api_align_signal      the public ``nadavca_amd.align_signal()`` call itself (host objects in, host arrays
+                        out: normalisation, two alignments, two linear re-fits) over a ``ReadBatch``.
 
 Rank 0 prints ONE JSON line with the contract keys plus
-  "roofline":     HBM roofline of the banded-DP kernel — algorithmic bytes (SURVEY.md §8d,
-                  B_align from the run's actual bands) / its HIP-event-timed launch duration
-  "cpu_baseline": the CPU oracle (oracle/, the reference compiled in place when oracle/_ref is
-                  present, else the C restatement) timed on this box's host cores on a bounded
-                  sample of the same reads.
+  "roofline":     the dominant kernel against the roofline that bounds it — align: HBM, algorithmic bytes
+                  (B_align from the run's actual bands) / its HIP-event-timed duration (the
+                  reverse-sweep and forward-sweep launches together); SNP kernels: FP64 vector issue
+  "e2e":          (cfg2_align, N=1) the same batch through the host-pointer entry point: H2D + plan + align
+                  + D2H, never `value`
+  "cpu_baseline": the CPU oracle (oracle/_ref = the reference compiled in place when present, else the C
+                  restatement) timed on this box's host cores on a bounded sample of the same reads.
 """
 import argparse
 import json
@@ -28,6 +40,9 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+# FP64 vector issue peak, measured (tools/ubench_valu.hip, profiles/ubench_valu_gfx950.txt): one v_fma_f64
+# wave-instruction per 2.24 ns and SIMD with 8 waves per SIMD; 1024 SIMDs x 64 lanes
+VALU_PEAK_TLANE = 1024 * 64 / 2.24e-9 / 1e12
 
 
 def cpu_baseline(batch, model, bandwidth, mel, workload, budget_reads_per_core=256):
@@ -43,7 +58,8 @@ def cpu_baseline(batch, model, bandwidth, mel, workload, budget_reads_per_core=2
     if hasattr(os, 'sched_getaffinity'):
         cores = max(1, min(cores, len(os.sched_getaffinity(0))))
     cores = int(os.environ.get('NADAVCA_CPU_THREADS', cores))
-    per_core = budget_reads_per_core if workload == 'cfg2_align' else (
+    align = workload in ('cfg2_align', 'cfg5_long', 'api_align_signal')
+    per_core = budget_reads_per_core if workload in ('cfg2_align', 'api_align_signal') else (
         1 if workload == 'cfg5_long' else max(8, budget_reads_per_core // 10))
     n = min(batch.n, cores * per_core)
     cases = batch.cases[:n]
@@ -51,7 +67,7 @@ def cpu_baseline(batch, model, bandwidth, mel, workload, budget_reads_per_core=2
     def work(c):
         a = (c['signal'], c['reference'], c['context_before'], c['context_after'],
              c['approximate_alignment'], bandwidth, mel, m)
-        if workload in ('cfg2_align', 'cfg5_long'):
+        if align:
             o.refine_alignment(*a, True)
         else:
             o.estimate_log_likelihoods(*a, True)
@@ -63,24 +79,24 @@ def cpu_baseline(batch, model, bandwidth, mel, workload, budget_reads_per_core=2
     dt = time.perf_counter() - t0
     return {'value': n / dt, 'unit': 'reads/s', 'cores': cores, 'kind': kind,
             'sample': '%d of the run\'s reads, %s, %d threads, %.1f s wall' % (
-                n, 'estimate_log_likelihoods(wobbling)' if workload == 'cfg3_snps' else 'refine_alignment(transitions)',
+                n, 'refine_alignment(transitions)' if align else 'estimate_log_likelihoods(wobbling)',
                 cores, dt),
             'per_core': n / dt / cores}
 
 
-def measured_traffic(workload, n_reads, key='bytes_per_launch'):
-    """HBM bytes per launch of the dominant kernel (or another recorded figure, `key`) from the
-    committed rocprofv3 PMC passes (profiles/*_hbm_traffic.json; counters cannot be read from inside
-    this process).  None when no measurement exists for this workload/size."""
+def profile_figure(workload, key):
+    """A figure that cannot be read from inside this process (HBM bytes, instruction counts: PMC counters)
+    from the newest committed rocprofv3 summary profiles/*_counters.json for this workload, per read, with
+    its provenance: -> (value per read or None, source file or None)."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_hbm_traffic.json')), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_counters.json')), reverse=True):
         try:
             t = json.load(open(path))
         except Exception:
             continue
-        if t.get('workload') == workload and int(t.get('reads_per_launch', -1)) == int(n_reads):
-            return t.get(key)
-    return None
+        if t.get('workload') == workload and key in t:
+            return t[key], os.path.relpath(path, ROOT)
+    return None, None
 
 
 def main():
@@ -88,9 +104,8 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--workload', default='cfg2_align', choices=['cfg2_align', 'cfg3_snps', 'cfg5_long'],
-                    help='cfg2_align (default, the headline), cfg3_snps, cfg5_long (BASELINE config 5 shape: '
-                         '~50k-sample reads, bandwidth 1000; refine_alignment)')
+    ap.add_argument('--workload', default='cfg2_align',
+                    choices=['cfg2_align', 'cfg3_snps', 'cfg4_consensus', 'cfg5_long', 'api_align_signal'])
     ap.add_argument('--reads', type=int, default=0, help='reads per GPU per step (default: the config size)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--slots', type=int, default=0)
@@ -113,30 +128,79 @@ def main():
     device = torch.device('cuda', local_rank)
 
     from nadavca_amd import dtw, synthetic, _lib
-    from nadavca_amd.device import DeviceBatch, refine_alignment_dev, estimate_log_likelihoods_dev
+    from nadavca_amd.device import (DeviceBatch, refine_alignment_dev, estimate_log_likelihoods_dev,
+                                    consensus_accumulate_dev, posterior_segments_dev)
 
-    wl = dict(synthetic.WORKLOADS[args.workload])
+    wname = args.workload
+    wl = dict(synthetic.WORKLOADS['cfg2_align' if wname == 'api_align_signal' else wname])
     n_reads = args.reads or wl.pop('n_reads')
     wl.pop('n_reads', None)
+    ref_len = wl.pop('reference_length', 10000)
     bandwidth, mel = wl['bandwidth'], 2
     model = synthetic.load_model_arrays()
     ctx = _lib.Context(local_rank)
     if args.slots:
         ctx.set_slots(args.slots)
     km = dtw.KmerModel(*model, context=ctx)
-    # every rank gets its own reads (seed offset by rank): weak scaling over independent reads
-    batch = synthetic.make_batch(n_reads, model, seed=1000 + rank, **wl)
-    dbatch = DeviceBatch(batch, device)
-    events = torch.zeros((dbatch.total_ref, 2), dtype=torch.int32, device=device)
-    is_align = args.workload in ('cfg2_align', 'cfg5_long')
-    ll = None if is_align else torch.zeros((dbatch.total_ref, 4), dtype=torch.float64, device=device)
-    status = torch.zeros(dbatch.n, dtype=torch.int32, device=device)
+    is_align = wname in ('cfg2_align', 'cfg5_long')
+    is_api = wname == 'api_align_signal'
+    extra = {}
 
-    def step():
-        if is_align:
-            refine_alignment_dev(dbatch, bandwidth, mel, km, True, events, status)
-        else:
-            estimate_log_likelihoods_dev(dbatch, bandwidth, mel, km, True, ll, status)
+    if is_api:
+        # the public call over a struct-of-arrays batch of simulated reads (nadavca_amd/readbatch.py)
+        from nadavca_amd.align_signal import align_signal_batch
+        rb, aligner, genome = synthetic.make_read_batch(n_reads, model, seed=1000 + rank, genome_length=ref_len)
+        batch = None
+
+        def step():
+            out = align_signal_batch(None, rb, kmer_model=km, aligner=aligner)
+            extra['reads_ok'] = int(out.n_aligned)
+        stats_of = lambda: ctx.last_batch_stats()
+    else:
+        # every rank gets its own reads (seed offset by rank): weak scaling over independent reads
+        batch = synthetic.make_batch(n_reads, model, seed=1000 + rank, **wl)
+        dbatch = DeviceBatch(batch, device)
+        events = torch.zeros((dbatch.total_ref, 2), dtype=torch.int32, device=device)
+        ll = None if is_align else torch.zeros((dbatch.total_ref, 4), dtype=torch.float64, device=device)
+        status = torch.zeros(dbatch.n, dtype=torch.int32, device=device)
+        if wname == 'cfg4_consensus':
+            # where each read's chunk lies on the 10 kb reference, its strand; the groups of overlapping
+            # chunks over ALL ranks' reads (fixed by the intervals: set up once, estimator.py:205-220)
+            from nadavca_amd.estimator import ProbabilityEstimator
+            from nadavca_amd import distributed as D
+            rng = np.random.default_rng(5000 + rank)
+            R = np.diff(batch.ref_off)
+            start = rng.integers(0, np.maximum(ref_len - R, 1))
+            rev = (np.arange(n_reads) % 2).astype(np.int32)
+            ranges = [(int(s), int(min(ref_len, s + r))) for s, r in zip(start, R)]
+            all_ranges = D.gather_ranges(ranges, device=device) if dist is not None else ranges
+            groups = ProbabilityEstimator.group_ranges(all_ranges)
+            seg = np.zeros(len(groups) + 1, dtype=np.int64)
+            np.cumsum([e - s for s, e in groups], out=seg[1:])
+            pos = np.concatenate([np.arange(s, e) for s, e in groups]) if groups else np.zeros(0, dtype=np.int64)
+            d_start = torch.from_numpy(start.astype(np.int64)).to(device)
+            d_rev = torch.from_numpy(rev).to(device)
+            d_pos = torch.from_numpy(pos).to(device)
+            d_seg = torch.from_numpy(seg).to(device)
+            d_refnum = torch.from_numpy(np.random.default_rng(4).integers(0, 4, ref_len).astype(np.int32)).to(device)[d_pos]
+            acc = torch.zeros((ref_len, 4), dtype=torch.float64, device=device)
+            cov = torch.zeros(ref_len, dtype=torch.int64, device=device)
+            extra['groups'] = len(groups)
+
+        def step():
+            if is_align:
+                refine_alignment_dev(dbatch, bandwidth, mel, km, True, events, status)
+            elif wname == 'cfg3_snps':
+                estimate_log_likelihoods_dev(dbatch, bandwidth, mel, km, True, ll, status)
+            else:
+                estimate_log_likelihoods_dev(dbatch, bandwidth, mel, km, True, ll, status)
+                acc.zero_()
+                cov.zero_()
+                consensus_accumulate_dev(ctx, dbatch, ll, d_start, d_rev, status, 10.0, ref_len, acc, cov)
+                tot = (acc, cov) if dist is None else D.reduce_consensus_tensors(acc, cov, dst=0)
+                if tot is not None and d_pos.numel():
+                    extra['posterior'] = posterior_segments_dev(ctx, tot[0][d_pos], d_refnum, d_seg, model[0], 0.001)
+        stats_of = lambda: ctx.last_batch_stats()
 
     def fence():
         torch.cuda.synchronize(device)
@@ -160,42 +224,85 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
-    n_ok = int((status == 0).sum().item())
+    n_ok = extra.get('reads_ok') if is_api else int((status == 0).sum().item())
     timing = ctx.timing_read()
-    stats = ctx.last_batch_stats()
+    stats = stats_of()
     if rank == 0:
         total_reads = n_reads * world * args.steps
-        out = {
-            'metric': {'cfg2_align': 'reads/sec (align_signal, ~4k-sample reads)',
-                       'cfg3_snps': 'reads/sec (estimate_snps log-likelihoods, ~4k-sample reads)',
-                       'cfg5_long': 'reads/sec (align_signal, ~50k-sample reads, wide band)'}[args.workload],
-            'value': total_reads / dt, 'unit': 'reads/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': 1000.0 * dt / args.steps, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': args.workload, 'reads_per_gpu_per_step': n_reads,
-                       'samples_per_read': round(dbatch.total_signal / n_reads, 1),
-                       'bases_per_read': round(dbatch.total_ref / n_reads, 1), 'bandwidth': bandwidth,
-                       'min_event_length': mel, 'kmer_model': 'packaged 6-mer', 'reads_ok': n_ok,
-                       'band_cells_per_read': round(stats['band_cells'] / n_reads, 1),
-                       'reads_redone_exact': stats['reads_redone_exact']},
-        }
-        kname = 'align' if is_align else 'ell_hyp'
+        metric = {'cfg2_align': 'reads/sec (align_signal, ~4k-sample reads)',
+                  'cfg3_snps': 'reads/sec (estimate_snps log-likelihoods, ~4k-sample reads)',
+                  'cfg4_consensus': 'reads/sec (estimate_snps independent=False: log-likelihoods + consensus '
+                                    'reduce + posterior, ~4k-sample reads)',
+                  'cfg5_long': 'reads/sec (align_signal, ~50k-sample reads, wide band)',
+                  'api_align_signal': 'reads/sec (nadavca_amd.align_signal() end to end, ~4k-sample reads)'}[wname]
+        cfg = {'workload': wname, 'reads_per_gpu_per_step': n_reads, 'bandwidth': bandwidth,
+               'min_event_length': mel, 'kmer_model': 'packaged 6-mer', 'reads_ok': n_ok}
+        if not is_api:
+            cfg.update({'samples_per_read': round(dbatch.total_signal / n_reads, 1),
+                        'bases_per_read': round(dbatch.total_ref / n_reads, 1),
+                        'band_cells_per_read': round(stats['band_cells'] / n_reads, 1)})
+        if is_align or is_api:
+            cfg.update({'reads_redone_exact': stats['reads_redone_exact'],
+                        # reads in which a path comparison fell inside the tie margin (include/nadavca_hip.h)
+                        'reads_tie_ambiguous': stats['reads_tie_ambiguous']})
+        if wname == 'cfg4_consensus':
+            cfg.update({'reference_length': ref_len, 'chunk_groups': extra.get('groups'),
+                        'collective': 'none (1 rank)' if dist is None else 'reduce(sum) of [L,5] f64 over RCCL'})
+        out = {'metric': metric, 'value': total_reads / dt, 'unit': 'reads/s', 'n_gpus': world,
+               'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1000.0 * dt / args.steps,
+               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
+               'data': 'synthetic', 'config': cfg}
+        kname = 'align' if (is_align or is_api) else 'ell_hyp'
         ms, launches = timing[kname]
-        if launches:
-            algo = (dbatch.algorithmic_bytes_align(stats['band_cells']) if is_align
-                    else dbatch.algorithmic_bytes_snp(stats['band_cells']))
+        per_kernel = {k: v[0] / max(v[1], 1) for k, v in timing.items() if v[1]}
+        if launches and is_align:
+            algo = dbatch.algorithmic_bytes_align(stats['band_cells'])
             sec = ms / 1000.0 / launches
             ach = algo / sec / 1e9
-            out['roofline'] = {'bound': 'hbm', 'kernel': kname, 'achieved': ach, 'peak': HBM_PEAK_GBS,
-                               'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
-                               'traffic': measured_traffic(args.workload, n_reads),
-                               # what actually limits the kernel: share of cycles its SIMDs issue
-                               # vector instructions (same PMC passes)
-                               'valu_busy': measured_traffic(args.workload, n_reads, 'valu_busy_frac'),
+            traffic, src = profile_figure(wname, 'hbm_bytes_per_read')
+            busy, _ = profile_figure(wname, 'valu_busy_frac')
+            out['roofline'] = {'bound': 'hbm', 'kernel': 'align (reverse-sweep launch + forward-sweep launch)',
+                               'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
+                               # PMC figures cannot be measured inside this run: taken from a committed
+                               # rocprofv3 summary of the same workload, scaled per read, and labelled
+                               'traffic': traffic * n_reads if traffic else None, 'valu_busy': busy,
+                               'from_profile': src,
                                'algorithmic_bytes_per_launch': algo, 'kernel_ms_per_launch': ms / launches,
-                               'all_kernels_ms': {k: v[0] / max(v[1], 1) for k, v in timing.items() if v[1]}}
-        if not args.no_cpu_baseline and world == 1:  # reported at N=1 only (contract)
-            out['cpu_baseline'] = cpu_baseline(batch, model, bandwidth, mel, args.workload)
+                               'all_kernels_ms': per_kernel}
+        elif launches and not is_api:
+            # FP64 vector issue: lane-instructions executed (committed PMC count per read) / time, against
+            # the measured issue rate of v_fma_f64 on all 1024 SIMDs
+            sec = ms / 1000.0 / launches
+            insts, src = profile_figure('cfg3_snps', 'valu_insts_per_read')
+            traffic, _ = profile_figure('cfg3_snps', 'hbm_bytes_per_read')
+            algo = dbatch.algorithmic_bytes_snp(stats['band_cells'])
+            rl = {'bound': 'valu', 'kernel': kname, 'unit': 'TFLOP/s', 'peak': VALU_PEAK_TLANE,
+                  'note': 'FP64 vector lane-instructions per second (an FMA counts once); peak = measured '
+                          'v_fma_f64 issue rate x 1024 SIMDs x 64 lanes', 'from_profile': src,
+                  'kernel_ms_per_launch': ms / launches, 'all_kernels_ms': per_kernel,
+                  'traffic': traffic * n_reads if traffic else None, 'algorithmic_bytes_per_launch': algo,
+                  'hbm_frac': algo / sec / 1e9 / HBM_PEAK_GBS}
+            if insts:
+                rl['achieved'] = insts * n_reads * 64 / sec / 1e12
+                rl['frac'] = rl['achieved'] / VALU_PEAK_TLANE
+            else:
+                rl['achieved'] = rl['frac'] = None
+            out['roofline'] = rl
+        elif is_api:
+            out['kernels_ms_per_step'] = {k: v[0] / args.steps for k, v in timing.items() if v[1]}
+        if wname == 'cfg2_align' and world == 1:
+            # T_e2e: host arrays in -> host arrays out through the host-pointer entry point
+            flat = dtw.FlatBatch.from_arrays(batch.signal, batch.sig_off, batch.reference, batch.ref_off,
+                                             batch.context_before, batch.cb_off, batch.context_after,
+                                             batch.ca_off, batch.anchors, batch.anc_off)
+            dtw.refine_alignment_flat(flat, bandwidth, mel, km, True)
+            t1 = time.perf_counter()
+            dtw.refine_alignment_flat(flat, bandwidth, mel, km, True)
+            te = time.perf_counter() - t1
+            out['e2e'] = {'reads_per_s': n_reads / te, 'ms': 1000.0 * te,
+                          'includes': 'H2D (pageable host arrays) + plan + align + D2H, nvk_refine_alignment_batch'}
+        if not args.no_cpu_baseline and world == 1 and batch is not None:  # reported at N=1 only (contract)
+            out['cpu_baseline'] = cpu_baseline(batch, model, bandwidth, mel, wname)
             out['gpu_over_cpu'] = out['value'] / world / out['cpu_baseline']['value']
         print(json.dumps(out), flush=True)
     if dist is not None:

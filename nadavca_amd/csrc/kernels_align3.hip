@@ -91,10 +91,16 @@ constexpr int GBIG = 1 << 24;  // scale of an empty running maximum (see the pat
 // produced) and the read is handed to the exact kernel — capping silently was tried and is WRONG: the
 // values that flush then can decide the path search although every row sum still checks out
 // (tests/dev/fuzz_parity.py seed 11, iteration 4230).
-constexpr int DMAX = 900;  // the density exponent (<= ~3) plus the move must stay inside the double range
+constexpr int DMAX = 1000;  // the density exponent (<= ~3) plus the move must stay inside the double range
+                            // (1000: a long read's reverse sweep ends in far-off-path cells that collapse by
+                            // ~28 bits per step — 906 bits in a 32-step period on BASELINE config 5 reads)
 constexpr int TARGET = 250; // exponent the largest live value is moved to
 #define HUGE_V 0x1.0p+900
 #define MASS_TOL 1e-9          // allowed relative spread of the rows' posterior mass
+#ifndef NVK_TIE_BITS
+#define NVK_TIE_BITS 24
+#endif
+#define TIE_FLAG_REL (1.0 / (double)(1ull << NVK_TIE_BITS))  // relative margin of the tie flag (xmath.h: near_tol)
 
 // The spill is addressed through a buffer resource: address = resource base (scalar) + scalar byte
 // offset of the step + per-lane byte offset (a constant vector register), so neither the store of the
@@ -621,6 +627,10 @@ __global__ __launch_bounds__(64, PHASE == 1 ? NVK_LB_REV : NVK_LB) void align3_k
           int mx = wave_max_i(ex);
           sc.d_next = (mx > -0x40000000) ? min(TARGET - mx, DMAX) : 0;
           suspect |= (mx > -0x40000000) && (TARGET - mx > DMAX);
+#ifdef NVK_FLAG_DEBUG
+          if (lane == 0 && (mx > -0x40000000) && (TARGET - mx > DMAX || !(o <= HUGE_V)))
+            printf("flag rev rd=%d u=%d/%d mx=%d L=%d RS=%d c=%d T=%d\n", rd, u, n_steps, mx, sc.L, RS, c, T);
+#endif
           if (PAIR) dsel = em ? sc.d_next : 0;  // (RS - 1 is odd: an evaluation step)
         }
         i -= 1;
@@ -889,7 +899,7 @@ __global__ __launch_bounds__(64, PHASE == 1 ? NVK_LB_REV : NVK_LB) void align3_k
             // the path would tie by their lost precision: this file is compiled with FP64 denormals
             // flushed, which makes them exact zeros.)
 #if !NVK_NO_TIEFLAG
-            amb |= __builtin_amdgcn_ballot_w64(fabs(tdiff) < dva * 0x1.0p-24);
+            amb |= __builtin_amdgcn_ballot_w64(fabs(tdiff) < dva * TIE_FLAG_REL);
 #endif
             if (upd) {
               bestn = __builtin_amdgcn_frexp_mant(dv);         // in [0.5, 1)
@@ -906,7 +916,7 @@ __global__ __launch_bounds__(64, PHASE == 1 ? NVK_LB_REV : NVK_LB) void align3_k
             if (top_live) {
               asm volatile("");
               const double da = ldexp(dpv, (fbest == 0.0) ? 0 : fG - Gd);
-              amb |= __builtin_amdgcn_ballot_w64(r == top && IN_BAND && fabs(da - fbest) < da * 0x1.0p-24);
+              amb |= __builtin_amdgcn_ballot_w64(r == top && IN_BAND && fabs(da - fbest) < da * TIE_FLAG_REL);
               if (r == top && IN_BAND && (da - fbest > fthr)) {
                 fbest = dpv;
                 fG = Gd;
@@ -935,6 +945,10 @@ __global__ __launch_bounds__(64, PHASE == 1 ? NVK_LB_REV : NVK_LB) void align3_k
               int mx = wave_max_i(ex);
               sc.d_next = (mx > -0x40000000) ? min(TARGET - mx, DMAX) : 0;
               suspect |= (mx > -0x40000000) && (TARGET - mx > DMAX);
+#ifdef NVK_FLAG_DEBUG
+              if (lane == 0 && (mx > -0x40000000) && (TARGET - mx > DMAX))
+                printf("flag fwd rd=%d u=%d/%d mx=%d L=%d RS=%d c=%d T=%d\n", rd, u, n_steps, mx, sc.L, RS, c, T);
+#endif
               if (PAIR) dsel = em ? sc.d_next : 0;
             }
             i += 1;
@@ -964,6 +978,10 @@ __global__ __launch_bounds__(64, PHASE == 1 ? NVK_LB_REV : NVK_LB) void align3_k
         smin = fmin(smin, __shfl_xor(smin, dlt, 64));
         smax = fmax(smax, __shfl_xor(smax, dlt, 64));
       }
+#ifdef NVK_FLAG_DEBUG
+      if (lane == 0 && !(smin > 0.0 && smax <= smin * (1.0 + MASS_TOL)))
+        printf("flag mass rd=%d smin=%g smax=%g c=%d T=%d\n", rd, smin, smax, c, T);
+#endif
       suspect |= !(smin > 0.0 && smax <= smin * (1.0 + MASS_TOL));
     }
     __syncthreads();

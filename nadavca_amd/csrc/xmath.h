@@ -13,6 +13,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#ifndef NVK_TIE_BITS
+#define NVK_TIE_BITS 24  // the tie flag's relative margin is 2^-NVK_TIE_BITS (near_tol)
+#endif
+
 namespace xm {
 
 constexpr int XZ = -(1 << 28);          // exponent carried by zeros
@@ -116,7 +120,7 @@ __device__ __forceinline__ bool gt_tol(X a, X b) {
 // (never for a zero a, nor against a zero b)
 __device__ __forceinline__ bool near_tol(X a, X b) {
   double am = ldexp(a.m, a.e - b.e);
-  return fabs(am - b.m) < am * 0x1.0p-24 && b.m != 0.0;
+  return fabs(am - b.m) < am * (1.0 / (double)(1ull << NVK_TIE_BITS)) && b.m != 0.0;
 }
 
 // c ? a : b.  (gfx950 note, tools/ubench_valu.hip: a v_cndmask_b32_e32 that re-reads an unchanged

@@ -35,6 +35,39 @@ class DeviceBatch:
         self.total_anchors = int(batch.anc_off[-1])
         torch.cuda.synchronize(self.device)
 
+    @classmethod
+    def from_windows(cls, signal_dev, sa, device):
+        """The DP inputs of ``readbatch.signal_alignments()`` (a SignalAlignmentBatch of tensors on ``device``)
+        with every read's signal window gathered ON THE DEVICE out of ``signal_dev`` (the normalised signals of
+        all reads end to end, f64 device tensor): no per-read array crosses PCIe."""
+        import torch
+        self = cls.__new__(cls)
+        self.torch = torch
+        self.device = torch.device(device)
+        dev = self.device
+        self.n = int(sa.live.numel())
+        win_len = sa.win_len.to(dev)
+        sig_off = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(win_len, 0)])
+        self.sig_off = sig_off
+        self.total_signal = int(sig_off[-1])
+        # source index of every window sample: its position in the batch + (window start - batch offset)
+        idx = torch.repeat_interleave(sa.win_start.to(dev) - sig_off[:-1], win_len, output_size=self.total_signal)
+        idx += torch.arange(self.total_signal, dtype=torch.int64, device=dev)
+        self.signal = signal_dev[idx]
+        del idx
+        nz = lambda t, m: t.to(dev).contiguous() if t.numel() else torch.zeros(m, dtype=t.dtype, device=dev)
+        self.reference = nz(sa.reference, 1)
+        self.ref_off = sa.ref_off.to(dev).contiguous()
+        self.context_before = nz(sa.context_before, 1)
+        self.cb_off = sa.cb_off.to(dev).contiguous()
+        self.context_after = nz(sa.context_after, 1)
+        self.ca_off = sa.ca_off.to(dev).contiguous()
+        self.anchors = nz(sa.anchors.reshape(-1), 2)
+        self.anc_off = sa.anc_off.to(dev).contiguous()
+        self.total_ref = int(sa.ref_off[-1])
+        self.total_anchors = int(sa.anc_off[-1])
+        return self
+
     def pointers(self):
         return [_dp(self.signal), _dp(self.sig_off), _dp(self.reference), _dp(self.ref_off),
                 _dp(self.context_before), _dp(self.cb_off), _dp(self.context_after), _dp(self.ca_off),
@@ -179,3 +212,37 @@ def refine_renorm_loop_dev(dbatch, bandwidth, min_event_length, kmer_model, mode
             new_status[keep] = status[keep]
             events, status = new_events, new_status
     return events, status, fits
+
+
+# ---- Chunk score accumulation and posterior, device-resident (estimator.py:199-236) ---------------------
+def consensus_accumulate_dev(context, dbatch, ll, chunk_start, reverse, status, normalization_event_length,
+                             ref_len, acc=None, cov=None):
+    """Normalise, strand-correct and scatter-add the per-read log-likelihood rows ``ll`` (as written by
+    ``estimate_log_likelihoods_dev``) into the per-position sums ``acc`` (ref_len, alphabet) f64 and the
+    coverage ``cov`` (ref_len,) i64 — torch tensors on the batch's device, created zeroed when not given,
+    accumulated into otherwise.  chunk_start i64 (n,), reverse i32 (n,), status i32 (n,) device tensors."""
+    torch = dbatch.torch
+    lib = _lib.load()
+    alpha = int(ll.shape[1])
+    if acc is None:
+        acc = torch.zeros((int(ref_len), alpha), dtype=torch.float64, device=dbatch.device)
+    if cov is None:
+        cov = torch.zeros(int(ref_len), dtype=torch.int64, device=dbatch.device)
+    _lib.check(lib.nvk_consensus_accumulate_dev(
+        context.handle, dbatch.n, dbatch.total_ref, alpha, _dp(ll), _dp(dbatch.reference), _dp(dbatch.ref_off),
+        _dp(chunk_start), _dp(reverse), _dp(status), float(normalization_event_length), int(ref_len),
+        _dp(acc), _dp(cov)), 'nvk_consensus_accumulate_dev')
+    return acc, cov
+
+
+def posterior_segments_dev(context, ll, reference_num, seg_off, k, snp_prior, out=None):
+    """``_compute_posterior`` for groups of positions laid end to end (device tensors: ll (len, alphabet) f64,
+    reference_num (len,) i32, seg_off (n_segments + 1,) i64) -> posterior (len, alphabet) f64."""
+    import torch
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty_like(ll)
+    _lib.check(lib.nvk_posterior_segments_dev(
+        context.handle, int(ll.shape[0]), int(seg_off.numel()) - 1, _dp(seg_off), int(ll.shape[1]), int(k),
+        float(snp_prior), _dp(ll), _dp(reference_num), _dp(out)), 'nvk_posterior_segments_dev')
+    return out

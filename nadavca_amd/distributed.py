@@ -72,12 +72,42 @@ def gather_ranges(ranges, device=None, group=None):
     return out
 
 
-def estimate_probabilities_distributed(estimator, reference, local_reads, dst=0, device=None, group=None):
-    """``ProbabilityEstimator.estimate_probabilities`` over the union of all ranks' reads.
-    Every rank passes its own shard; the Chunk list is returned on ``dst`` (None elsewhere)."""
-    acc, cov, ranges = estimator.local_consensus(reference, local_reads)
+def reduce_consensus_tensors(acc, cov, dst=0, group=None):
+    """The same exchange for torch tensors that already live where the collective runs (cuda tensors with
+    the nccl/RCCL backend: the per-position sums never leave the device; cpu tensors with gloo): ONE
+    reduce(sum) of the packed (L, alphabet + 1) f64 buffer.  -> (acc, cov) tensors on ``dst``, None elsewhere."""
+    torch, dist = _torch_dist()
+    packed = torch.cat([acc.to(torch.float64), cov.to(torch.float64).unsqueeze(1)], dim=1).contiguous()
+    dist.reduce(packed, dst=dst, op=dist.ReduceOp.SUM, group=group)
+    if dist.get_rank(group) != dst:
+        return None
+    return packed[:, :-1].contiguous(), torch.round(packed[:, -1]).to(torch.int64)
+
+
+def merge_consensus(acc, cov, ranges, dst=0, device=None, group=None):
+    """The exchange step of ``independent=False`` and nothing else (no GPU involved: covered by the gloo
+    tests): every rank contributes its per-position sums, coverage and chunk intervals; ``dst`` receives
+    what the posterior needs — (total acc, total cov, groups, seg_off, ll laid end to end per group) — the
+    other ranks None.  Grouping follows estimator.py:205-220 over the union of all ranks' intervals."""
+    from .estimator import ProbabilityEstimator
     all_ranges = gather_ranges(ranges, device=device, group=group)
     total = reduce_consensus(acc, cov, dst=dst, device=device, group=group)
     if total is None:
         return None
-    return estimator.posterior_groups(reference, total[0], total[1], all_ranges)
+    tacc, tcov = total
+    groups = ProbabilityEstimator.group_ranges(all_ranges)
+    seg_off = np.zeros(len(groups) + 1, dtype=np.int64)
+    np.cumsum([e - s for s, e in groups], out=seg_off[1:])
+    ll_cat = np.concatenate([tacc[s:e] for s, e in groups]) if groups else np.zeros((0, tacc.shape[1]))
+    return tacc, tcov, groups, seg_off, ll_cat
+
+
+def estimate_probabilities_distributed(estimator, reference, local_reads, dst=0, device=None, group=None):
+    """``ProbabilityEstimator.estimate_probabilities`` over the union of all ranks' reads.
+    Every rank passes its own shard; the Chunk list is returned on ``dst`` (None elsewhere)."""
+    acc, cov, ranges = estimator.local_consensus(reference, local_reads)
+    merged = merge_consensus(acc, cov, ranges, dst=dst, device=device, group=group)
+    if merged is None:
+        return None
+    tacc, tcov, groups, seg_off, ll_cat = merged
+    return estimator.posterior_of_groups(reference, tcov, groups, seg_off, ll_cat)

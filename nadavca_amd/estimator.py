@@ -264,19 +264,25 @@ class ProbabilityEstimator:
         acc, cov = self._accumulate(live, batch, ll, status, chunk_start, len(reference))
         return acc, cov, [tuple(int(v) for v in live[j].apx.reference_range) for j in keep]
 
+    def posterior_of_groups(self, reference, cov, groups, seg_off, ll_cat):
+        """Posterior of already grouped sums (all groups in one launch, laid end to end) -> Chunk list."""
+        if not groups:
+            return []
+        ref_cat = numpy.concatenate([Genome.to_numerical(reference[s:e]) for s, e in groups])
+        post = self._posterior(ll_cat, ref_cat, seg_off)
+        return [Chunk(s, e, post[seg_off[g]:seg_off[g + 1]], cov[s:e].copy())
+                for g, (s, e) in enumerate(groups)]
+
     def posterior_groups(self, reference, acc, cov, ranges):
         """Group the chunk intervals and turn the summed log-likelihoods into posteriors
-        (estimator.py:205-235): all groups in one launch, laid end to end."""
+        (estimator.py:205-235)."""
         groups = self.group_ranges(ranges)
         if not groups:
             return []
         seg_off = numpy.zeros(len(groups) + 1, dtype=numpy.int64)
         numpy.cumsum([e - s for s, e in groups], out=seg_off[1:])
         ll_cat = numpy.concatenate([acc[s:e] for s, e in groups])
-        ref_cat = numpy.concatenate([Genome.to_numerical(reference[s:e]) for s, e in groups])
-        post = self._posterior(ll_cat, ref_cat, seg_off)
-        return [Chunk(s, e, post[seg_off[g]:seg_off[g + 1]], cov[s:e].copy())
-                for g, (s, e) in enumerate(groups)]
+        return self.posterior_of_groups(reference, cov, groups, seg_off, ll_cat)
 
     def estimate_probabilities(self, reference, reads):
         """Consensus over all reads (estimator.py:199-236) -> list of Chunk(start, end, posterior,

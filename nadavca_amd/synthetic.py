@@ -136,6 +136,7 @@ def make_batch(n_reads, model, seed=0, R=400, R_spread=40, **kw):
 WORKLOADS = {
     'cfg2_align': dict(n_reads=10000, R=400, R_spread=40, bandwidth=150),
     'cfg3_snps': dict(n_reads=10000, R=400, R_spread=40, bandwidth=150),
+    'cfg4_consensus': dict(n_reads=10000, R=400, R_spread=40, bandwidth=150, reference_length=10000),
     'cfg5_long': dict(n_reads=64, R=5000, R_spread=500, bandwidth=1000),
 }
 
@@ -233,3 +234,25 @@ def make_synthetic_aligner(base_class, reference):
             return np.array(s['base_mapping'], dtype=int), s['reverse'], 'synthetic'
 
     return SyntheticAligner(reference)
+
+
+def make_read_batch(n, model, seed=0, genome_length=10000, raw_dtype=np.int16, **kw):
+    """``n`` simulated reads against one random genome as a struct-of-arrays ``readbatch.ReadBatch`` plus the
+    batch aligner that knows their true base mapping: -> (ReadBatch, SyntheticBatchAligner, genome codes).
+    Raw signals are ADC-like counts (``raw_dtype`` int16, as fast5 files hold them)."""
+    from .readbatch import ReadBatch, BaseAlignmentBatch, SyntheticBatchAligner
+    genome = np.random.default_rng(seed).integers(0, 4, genome_length).astype(np.int32)
+    specs = [make_read_spec(np.random.default_rng([seed, i]), genome, model, i, **kw) for i in range(n)]
+    inv = {'A': 0, 'C': 1, 'G': 2, 'T': 3}
+    off = lambda xs: np.concatenate([[0], np.cumsum([len(x) for x in xs])]).astype(np.int64)
+    raws = [np.rint(s['raw_signal']).astype(raw_dtype) if np.issubdtype(raw_dtype, np.integer)
+            else np.asarray(s['raw_signal'], dtype=raw_dtype) for s in specs]
+    seqs = [np.array([inv[b] for b in s['sequence']], dtype=np.int32) for s in specs]
+    maps = [sorted(s['sequence_to_signal_mapping'].items()) for s in specs]
+    rb = ReadBatch(np.concatenate(raws), off(raws), np.concatenate(seqs), off(seqs),
+                   np.array([k for m in maps for k, _ in m], dtype=np.int64),
+                   np.array([v for m in maps for _, v in m], dtype=np.int64), off(maps))
+    bms = [np.asarray(s['base_mapping'], dtype=np.int64).reshape(-1, 2) for s in specs]
+    ba = BaseAlignmentBatch(np.concatenate([b[:, 0] for b in bms]), np.concatenate([b[:, 1] for b in bms]),
+                            off(bms), np.array([s['reverse'] for s in specs], dtype=bool))
+    return rb, SyntheticBatchAligner(genome, ba), genome

@@ -50,6 +50,70 @@ def test_two_rank_consensus_exchange(tmp_path):
     assert (int(r0['lo']), int(r0['hi']), int(r1['lo']), int(r1['hi'])) == (0, 6, 6, 11)
 
 
+def _synthetic_chunks(n_reads=48, L=600, seed=7):
+    """Per-read (start, end, normalised log-likelihood rows) as ``_estimate_log_likelihoods`` would hand them
+    to the consensus sum (estimator.py:112-121): overlapping intervals, a gap, touching intervals."""
+    rng = np.random.default_rng(seed)
+    chunks = []
+    for i in range(n_reads):
+        start = int(rng.integers(0, 250)) if i % 3 else int(rng.integers(330, 520))
+        end = min(L, start + int(rng.integers(40, 90)))
+        chunks.append((start, end, rng.normal(-3.0, 2.0, size=(end - start, 4))))
+    chunks.append((300, 330, rng.normal(size=(30, 4))))   # touches the next group's first start
+    return chunks, L
+
+
+def _local_sums(chunks, L):
+    acc = np.zeros((L, 4))
+    cov = np.zeros(L, dtype=np.int64)
+    for s, e, v in chunks:
+        acc[s:e] += v
+        cov[s:e] += 1
+    return acc, cov, [(s, e) for s, e, _ in chunks]
+
+
+def _merge_worker(rank, world, port, tmp):
+    import torch
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from nadavca_amd import distributed as D
+    chunks, L = _synthetic_chunks()
+    mine = D.shard(chunks, rank, world)                      # contiguous blocks of reads per rank
+    acc, cov, ranges = _local_sums(mine, L)
+    merged = D.merge_consensus(acc, cov, ranges, dst=0)
+    tens = D.reduce_consensus_tensors(torch.from_numpy(acc), torch.from_numpy(cov), dst=0)
+    if rank == 0:
+        tacc, tcov, groups, seg_off, ll_cat = merged
+        np.savez(os.path.join(tmp, 'merged.npz'), tacc=tacc, tcov=tcov, groups=np.array(groups), seg_off=seg_off,
+                 ll_cat=ll_cat, t_acc=tens[0].numpy(), t_cov=tens[1].numpy())
+    else:
+        assert merged is None and tens is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_merge_equals_single_rank(tmp_path):
+    """The exchange step of estimate_snps(independent=False) end to end on two gloo ranks — local sums of
+    each rank's shard, interval all-gather, ONE packed reduce, grouping, the posterior's inputs — against
+    the same over all reads on one rank (estimator.py:205-235): sums to 1e-12, everything else exact."""
+    import torch.multiprocessing as mp
+    from nadavca_amd.estimator import ProbabilityEstimator
+    port = _free_port()
+    mp.spawn(_merge_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = np.load(tmp_path / 'merged.npz')
+    chunks, L = _synthetic_chunks()
+    acc, cov, ranges = _local_sums(chunks, L)
+    groups = ProbabilityEstimator.group_ranges(ranges)
+    seg_off = np.concatenate([[0], np.cumsum([e - s for s, e in groups])])
+    assert np.allclose(got['tacc'], acc, rtol=0, atol=1e-12) and np.array_equal(got['tcov'], cov)
+    assert np.allclose(got['t_acc'], acc, rtol=0, atol=1e-12) and np.array_equal(got['t_cov'], cov)
+    assert [tuple(g) for g in got['groups'].tolist()] == groups and len(groups) >= 2
+    assert np.array_equal(got['seg_off'], seg_off)
+    assert np.allclose(got['ll_cat'], np.concatenate([acc[s:e] for s, e in groups]), rtol=0, atol=1e-12)
+
+
 def test_group_ranges_strict_overlap():
     from nadavca_amd.estimator import ProbabilityEstimator
     g = ProbabilityEstimator.group_ranges

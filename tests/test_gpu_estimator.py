@@ -102,3 +102,29 @@ def test_align_signal_renorm_loop(fx, km):
         assert np.array_equal(alignment, fx.z['as_r%d_alignment' % i])
         assert np.allclose(read.normalized_signal[:64], fx.z['as_r%d_norm_head' % i], rtol=1e-10, atol=1e-12)
         assert np.allclose(np.sum(read.normalized_signal), fx.z['as_r%d_norm_checksum' % i], rtol=1e-9)
+
+
+def test_align_signal_batch_equals_the_per_read_workflow(km):
+    """``align_signal_batch`` (struct-of-arrays in, no per-read Python, windows cut on the device) against
+    ``align_signal`` (the reference-shaped generator, pinned to the reference's Python by the G7 fixture
+    above): the same (R, 3) rows, the same rescaled normalised signals."""
+    from nadavca_amd import synthetic
+    from nadavca_amd.alignment import ApproximateAligner
+    from nadavca_amd.align_signal import align_signal, align_signal_batch
+    from nadavca_amd.readbatch import ReadBatch, BaseAlignmentBatch, SyntheticBatchAligner
+    model = synthetic.load_model_arrays()
+    genome = np.random.default_rng(21).integers(0, 4, 4000).astype(np.int32)
+    specs = [synthetic.make_read_spec(np.random.default_rng([22, i]), genome, model, i, length=220, spread=40,
+                                      substitution_rate=0.05) for i in range(40)]
+    reads = synthetic.reads_from_specs(specs)
+    aligner = synthetic.make_synthetic_aligner(ApproximateAligner, np.array(list('ACGT'))[genome])
+    per_read = list(align_signal(None, reads, kmer_model=km, aligner=aligner))
+    rb = ReadBatch.from_reads(synthetic.reads_from_specs(specs))
+    bms = [np.asarray(s['base_mapping'], dtype=np.int64).reshape(-1, 2) for s in specs]
+    ba = BaseAlignmentBatch(np.concatenate([b[:, 0] for b in bms]), np.concatenate([b[:, 1] for b in bms]),
+                            np.concatenate([[0], np.cumsum([len(b) for b in bms])]), [s['reverse'] for s in specs])
+    out = align_signal_batch(None, rb, kmer_model=km, aligner=SyntheticBatchAligner(genome, ba))
+    assert out.n_aligned == len(per_read) == 40 and out.live.tolist() == list(range(40))
+    for j, (read, (apx, rows)) in enumerate(per_read):
+        assert np.array_equal(out.alignment_of(j), rows)
+        assert np.array_equal(out.normalized_signal(j), read.normalized_signal)

@@ -165,3 +165,28 @@ def test_config5_shape_log_likelihoods_equal_the_oracle(oracle_port, cfg5_cases)
     assert np.array_equal(np.isneginf(got), np.isneginf(exp)) and not np.any(np.isnan(got))
     fin = np.isfinite(exp)
     assert np.allclose(got[fin], exp[fin], rtol=1e-9, atol=1e-9)
+
+
+def test_quantised_signals_equal_the_oracle_and_are_flagged(oracle_port):
+    """Signals as a sequencer delivers them: integer ADC counts, so a read holds each normalised value many
+    times.  Equal samples make equal densities, and path scores then tie EXACTLY at some comparison of almost
+    every read (the flag fires) — for the engine and for the reference alike.  Such exact ties are resolved by
+    "first maximum wins" on both sides: the events still equal the reference's on every read here."""
+    from nadavca_amd import dtw, synthetic, _lib
+    model = synthetic.load_model_arrays()
+    ctx = _lib.default_context()
+    mg = dtw.KmerModel(*model, context=ctx)
+    mo = oracle_port.KmerModel(*model)
+    batch = synthetic.make_batch(600, model, seed=31, R=300, R_spread=30, bandwidth=120)
+    for c in batch.cases:
+        c['signal'] = np.round(c['signal'] * 12.0) / 12.0        # 12 ADC counts per unit, as synthetic raw signals
+    reads = _reads(batch.cases)
+    for tr in (True, False):
+        got = dtw.refine_alignment_batch(reads, 120, 2, mg, tr)
+        flags = ctx.last_tie_flags(len(reads))
+        exp = _oracle_refine(oracle_port, mo, batch.cases, 120, 2, tr)
+        diff = np.array([not _same(g, e) for g, e in zip(got, exp)])
+        print('quantised signals, transitions=%s: %d reads, %d flagged, %d differ from the reference'
+              % (tr, len(reads), int((flags != 0).sum()), int(diff.sum())))
+        assert not np.any(diff & (flags == 0))
+        assert diff.sum() == 0
