@@ -109,6 +109,8 @@ def main():
     ap.add_argument('--reads', type=int, default=0, help='reads per GPU per step (default: the config size)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--slots', type=int, default=0)
+    ap.add_argument('--k', type=int, default=0, help='use a synthetic k-mer table of this size (e.g. 10: the size of the '
+                    "reference's coded default table, 4^10 rows) instead of the packaged 6-mer table")
     args = ap.parse_args()
 
     import torch
@@ -137,7 +139,8 @@ def main():
     wl.pop('n_reads', None)
     ref_len = wl.pop('reference_length', 10000)
     bandwidth, mel = wl['bandwidth'], 2
-    model = synthetic.load_model_arrays()
+    model = synthetic.synth_model_arrays(7, k=args.k, central=(args.k - 1) // 2) if args.k else synthetic.load_model_arrays()
+    model_name = 'synthetic %d-mer' % args.k if args.k else 'packaged 6-mer'
     ctx = _lib.Context(local_rank)
     if args.slots:
         ctx.set_slots(args.slots)
@@ -236,7 +239,7 @@ def main():
                   'cfg5_long': 'reads/sec (align_signal, ~50k-sample reads, wide band)',
                   'api_align_signal': 'reads/sec (nadavca_amd.align_signal() end to end, ~4k-sample reads)'}[wname]
         cfg = {'workload': wname, 'reads_per_gpu_per_step': n_reads, 'bandwidth': bandwidth,
-               'min_event_length': mel, 'kmer_model': 'packaged 6-mer', 'reads_ok': n_ok}
+               'min_event_length': mel, 'kmer_model': model_name, 'reads_ok': n_ok}
         if not is_api:
             cfg.update({'samples_per_read': round(dbatch.total_signal / n_reads, 1),
                         'bases_per_read': round(dbatch.total_ref / n_reads, 1),

@@ -38,7 +38,7 @@
 //     at the same cell, handed over through the LDS ring with the emitting value, which is normalised
 //     at EVERY hand-over (a dominating value passes its mantissa on; a systematic factor per hand-over
 //     would compound to 2^-R or 2^+R along the lanes).
-// The exact variant (NADAVCA_ELL_KERNEL=1, and k-mers longer than 6) is the original formulation with
+// The exact variant (NADAVCA_ELL_KERNEL=1) is the original formulation with
 // two polynomial densities per lane and LDS hand-over; both agree to ~1e-15 relative
 // (tools/dbg_ell.py, tests/test_gpu_ell.py).
 //
@@ -57,7 +57,9 @@ using xm::X;
 constexpr int CH = 128;    // signal refill chunk (samples)
 constexpr int TABN = 128;  // descriptor window (two 64-position blocks)
 constexpr int PF = 4;      // phase C prefetch depth (steps)
-constexpr int GL = 8;      // lanes per hypothesis group (exact: k + 1 <= GL; fast: k + 2 <= GL)
+// lanes per hypothesis group (template parameter GL of the kernel): 8 for k-mers up to 6 (8 hypotheses per
+// wave step), 16 for longer ones (4 per step; a group is then one DPP row) — the fast phase needs k + 2
+// lanes per group, the exact one k + 1
 constexpr int HRS = 16;    // fast phase C: steps between mantissa normalisations
 #define EXPM2_D 0x1.152aaa3bf81ccp-3  // exp(-2), see expm2()
 
@@ -457,7 +459,7 @@ __device__ void sweep_fast(const FusedParam *desc, int R, int N, int c, const do
   }
 }
 
-template <int MEL, bool FAST>
+template <int MEL, bool FAST, int GL>
 __global__ __launch_bounds__(64, 3) void ell_kernel(EllArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double *etab = reinterpret_cast<double *>(smem);
@@ -804,14 +806,15 @@ int launch_ell(nvk_ctx *ctx, const DeviceModel &dm, const BatchArgs &a, int wobb
     nvk_set_error("min_event_length %d outside the compiled range 0..4", mel);
     return NVK_ERR_UNSUPPORTED;
   }
-  if (dm.k + 1 > GL) {
-    nvk_set_error("k-mer size %d needs %d lanes per hypothesis, compiled limit is %d", dm.k, dm.k + 1, GL);
+  if (dm.k + 1 > 16) {
+    nvk_set_error("k-mer size %d needs %d lanes per hypothesis, compiled limit is 16", dm.k, dm.k + 1);
     return NVK_ERR_UNSUPPORTED;
   }
   // default: the fast variant; NADAVCA_ELL_KERNEL=1 (or a k-mer too long for its lane layout)
   // selects the original formulation
   const char *force = getenv("NADAVCA_ELL_KERNEL");
-  const bool fast = !(force && force[0] == '1') && dm.k + 2 <= GL;
+  const bool fast = !(force && force[0] == '1') && dm.k + 2 <= 16;
+  const bool wide_groups = fast ? (dm.k + 2 > 8) : (dm.k + 1 > 8);  // 16 lanes per hypothesis instead of 8
   // rings sized by the largest skew of the batch that still fits 160 KB of LDS; a read beyond that gets
   // NVK_READ_TOO_WIDE and the others complete
   int H = 2, SR = 256;
@@ -876,13 +879,19 @@ int launch_ell(nvk_ctx *ctx, const DeviceModel &dm, const BatchArgs &a, int wobb
 
   void (*kern_fast)(EllArgs) = nullptr;
   void (*kern_exact)(EllArgs) = nullptr;
+#define ELL_PICK(M)                                                                              \
+  do {                                                                                           \
+    if (wide_groups) { kern_fast = ell_kernel<M, true, 16>; kern_exact = ell_kernel<M, false, 16>; } \
+    else { kern_fast = ell_kernel<M, true, 8>; kern_exact = ell_kernel<M, false, 8>; }           \
+  } while (0)
   switch (mel) {
-    case 0: kern_fast = ell_kernel<0, true>; kern_exact = ell_kernel<0, false>; break;
-    case 1: kern_fast = ell_kernel<1, true>; kern_exact = ell_kernel<1, false>; break;
-    case 2: kern_fast = ell_kernel<2, true>; kern_exact = ell_kernel<2, false>; break;
-    case 3: kern_fast = ell_kernel<3, true>; kern_exact = ell_kernel<3, false>; break;
-    default: kern_fast = ell_kernel<4, true>; kern_exact = ell_kernel<4, false>; break;
+    case 0: ELL_PICK(0); break;
+    case 1: ELL_PICK(1); break;
+    case 2: ELL_PICK(2); break;
+    case 3: ELL_PICK(3); break;
+    default: ELL_PICK(4); break;
   }
+#undef ELL_PICK
   if (lds > 64 * 1024) {
     NVK_HIP(hipFuncSetAttribute((const void *)kern_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     NVK_HIP(hipFuncSetAttribute((const void *)kern_exact, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -152,11 +152,13 @@ print("ELL-EXACT-OK")
     assert p.returncode == 0 and 'ELL-EXACT-OK' in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
 
 
-@pytest.mark.parametrize('k,central', [(7, 3), (4, 0), (2, 1)])
+@pytest.mark.parametrize('k,central', [(7, 3), (4, 0), (2, 1), (8, 3), (10, 4), (10, 0)])
 def test_ell_other_kmer_sizes(dtw, oracle_port, k, central):
-    """k-mer sizes other than the packaged 6: k = 7 does not fit the default hypothesis phase's lane
-    layout (k + 2 lanes of 8) and is served by the original one; small k and off-centre k-mers move the
-    range of rows a substitution touches."""
+    """k-mer sizes other than the packaged 6: from k = 7 on a hypothesis takes a group of 16 lanes instead of
+    8 (k + 2 lanes: the k-mer before the first touched position, the <= k touched positions, the closing
+    lane) — k = 10 is the size of the table the reference names as its default
+    (/root/reference/nadavca/defaults.py:4, a 4^10-row table; kmer_model.cpp:22-30 takes any k); small k and
+    off-centre k-mers move the range of rows a substitution touches."""
     from nadavca_amd import synthetic
     model = synthetic.synth_model_arrays(31 + k, k=k, central=central)
     mg = dtw.KmerModel(*model)
