@@ -246,7 +246,8 @@ __global__ __launch_bounds__(256) void lane3_kernel(const ReadMeta *metas, const
 // steps old, i.e. in slot (su - D) mod H)
 #define TAKE_LANE(l)                                                                   \
   do {                                                                                 \
-    mean = (l).mean; ac2 = (l).ac; mc2 = (l).mc; melr = (l).mg & 15;                   \
+    if (!PAIR || em) { mean = (l).mean; ac2 = (l).ac; mc2 = (l).mc; }  /* (a transition lane keeps its partner's) */ \
+    melr = (l).mg & 15;                                                                \
     D = ((l).mg >> 4) & 255;                                                           \
     bs = (l).bs; pA = (l).pA; pW = (l).pW;                                             \
     ra = (int)min((unsigned)(su - D), (unsigned)(su - D + H)) * 64 + nb;               \
@@ -513,16 +514,20 @@ __global__ __launch_bounds__(64, PHASE == 1 ? NVK_LB_REV : NVK_LB) void align3_k
             }
           }
           if (PAIR) {
-            // every transition lane takes its partner's (possibly new) row constants and sample index;
-            // on an even step its `e` is the partner's density of the NEXT step, evaluated one step ago
-            // with the constants of then: evaluate it again (the same value unless the partner switched)
-            const double pmn = pair_swap(mean), pac = pair_swap(ac2), pmc = pair_swap(mc2);
-            const int ip = pair_swap(i);
-            if (!em) { mean = pmn; ac2 = pac; mc2 = pmc; }
-            const int odd = u & 1;
-            redo = em ? redo : !odd;
-            if (redo) e = density(ring[(em ? i : ip - 1) & RM], mean, ac2, mc2, em ? shift_now : 0, etab);
-            ia = (em ? i - 1 : ip - 2) - (odd ? 0 : 1);
+            // when an EMITTING lane has switched: every transition lane takes its partner's (possibly
+            // new) row constants and sample index; on an even step its `e` is the partner's density of
+            // the NEXT step, evaluated one step ago with the constants of then: evaluate it again (the
+            // same value unless the partner switched).  (A transition lane's own switch changes nothing
+            // about the densities.)
+            if (__any(redo && em)) {
+              const double pmn = pair_swap(mean), pac = pair_swap(ac2), pmc = pair_swap(mc2);
+              const int ip = pair_swap(i);
+              if (!em) { mean = pmn; ac2 = pac; mc2 = pmc; }
+              const int odd = u & 1;
+              redo = em ? redo : !odd;
+              if (redo) e = density(ring[(em ? i : ip - 1) & RM], mean, ac2, mc2, em ? shift_now : 0, etab);
+              ia = (em ? i - 1 : ip - 2) - (odd ? 0 : 1);
+            }
           } else if (redo) {
             e = density(ring[i & RM], mean, ac2, mc2, shift_now, etab);
           }
@@ -794,13 +799,15 @@ __global__ __launch_bounds__(64, PHASE == 1 ? NVK_LB_REV : NVK_LB) void align3_k
                 }
               }
               if (PAIR) {  // see the reverse sweep
-                const double pmn = pair_swap(mean), pac = pair_swap(ac2), pmc = pair_swap(mc2);
-                const int ip = pair_swap(i);
-                if (!em) { mean = pmn; ac2 = pac; mc2 = pmc; }
-                const int odd = u & 1;
-                redo = em ? redo : !odd;
-                if (redo) e = density(ring[(em ? i - 1 : ip) & RM], mean, ac2, mc2, em ? shift_now : 0, etab);
-                ia = (em ? i : ip + 1) + (odd ? 0 : 1);
+                if (__any(redo && em)) {
+                  const double pmn = pair_swap(mean), pac = pair_swap(ac2), pmc = pair_swap(mc2);
+                  const int ip = pair_swap(i);
+                  if (!em) { mean = pmn; ac2 = pac; mc2 = pmc; }
+                  const int odd = u & 1;
+                  redo = em ? redo : !odd;
+                  if (redo) e = density(ring[(em ? i - 1 : ip) & RM], mean, ac2, mc2, em ? shift_now : 0, etab);
+                  ia = (em ? i : ip + 1) + (odd ? 0 : 1);
+                }
               } else if (redo) {
                 e = density(ring[(i - 1) & RM], mean, ac2, mc2, shift_now, etab);
               }
