@@ -105,7 +105,10 @@ def main():
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--workload', default='cfg2_align',
-                    choices=['cfg2_align', 'cfg3_snps', 'cfg4_consensus', 'cfg5_long', 'api_align_signal'])
+                    choices=['cfg2_align', 'cfg3_snps', 'cfg4_consensus', 'cfg5_long', 'api_align_signal',
+                             'api_estimate_snps'])
+    ap.add_argument('--no-tweak', action='store_true', help='api_estimate_snps: tweak_signal_normalization off')
+    ap.add_argument('--fit-workers', type=int, default=16, help='api_estimate_snps: processes for the spline fits')
     ap.add_argument('--reads', type=int, default=0, help='reads per GPU per step (default: the config size)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--slots', type=int, default=0)
@@ -134,7 +137,7 @@ def main():
                                     consensus_accumulate_dev, posterior_segments_dev)
 
     wname = args.workload
-    wl = dict(synthetic.WORKLOADS['cfg2_align' if wname == 'api_align_signal' else wname])
+    wl = dict(synthetic.WORKLOADS['cfg2_align' if wname.startswith('api_') else wname])
     n_reads = args.reads or wl.pop('n_reads')
     wl.pop('n_reads', None)
     ref_len = wl.pop('reference_length', 10000)
@@ -146,7 +149,7 @@ def main():
         ctx.set_slots(args.slots)
     km = dtw.KmerModel(*model, context=ctx)
     is_align = wname in ('cfg2_align', 'cfg5_long')
-    is_api = wname == 'api_align_signal'
+    is_api = wname.startswith('api_')
     extra = {}
 
     if is_api:
@@ -155,9 +158,21 @@ def main():
         rb, aligner, genome = synthetic.make_read_batch(n_reads, model, seed=1000 + rank, genome_length=ref_len)
         batch = None
 
-        def step():
-            out = align_signal_batch(None, rb, kmer_model=km, aligner=aligner)
-            extra['reads_ok'] = int(out.n_aligned)
+        if wname == 'api_align_signal':
+            def step():
+                out = align_signal_batch(None, rb, kmer_model=km, aligner=aligner)
+                extra['reads_ok'] = int(out.n_aligned)
+        else:
+            from nadavca_amd.estimate_snps import estimate_snps_batch
+            from nadavca_amd.align_signal import _load_config
+            from nadavca_amd import defaults
+            cfg_snps = dict(_load_config(defaults.CONFIG_FILE), tweak_signal_normalization=not args.no_tweak)
+
+            def step():
+                chunks = estimate_snps_batch(genome, rb, config=cfg_snps, kmer_model=km, aligner=aligner,
+                                             fit_workers=args.fit_workers)
+                extra['reads_ok'] = n_reads
+                extra['chunks'] = len(chunks)
         stats_of = lambda: ctx.last_batch_stats()
     else:
         # every rank gets its own reads (seed offset by rank): weak scaling over independent reads
@@ -237,14 +252,19 @@ def main():
                   'cfg4_consensus': 'reads/sec (estimate_snps independent=False: log-likelihoods + consensus '
                                     'reduce + posterior, ~4k-sample reads)',
                   'cfg5_long': 'reads/sec (align_signal, ~50k-sample reads, wide band)',
-                  'api_align_signal': 'reads/sec (nadavca_amd.align_signal() end to end, ~4k-sample reads)'}[wname]
+                  'api_align_signal': 'reads/sec (nadavca_amd.align_signal() end to end, ~4k-sample reads)',
+                  'api_estimate_snps': 'reads/sec (nadavca_amd.estimate_snps(independent=False) end to end, '
+                                       '~4k-sample reads)'}[wname]
         cfg = {'workload': wname, 'reads_per_gpu_per_step': n_reads, 'bandwidth': bandwidth,
                'min_event_length': mel, 'kmer_model': model_name, 'reads_ok': n_ok}
         if not is_api:
             cfg.update({'samples_per_read': round(dbatch.total_signal / n_reads, 1),
                         'bases_per_read': round(dbatch.total_ref / n_reads, 1),
                         'band_cells_per_read': round(stats['band_cells'] / n_reads, 1)})
-        if is_align or is_api:
+        if wname == 'api_estimate_snps':
+            cfg.update({'tweak_signal_normalization': not args.no_tweak, 'fit_workers': args.fit_workers,
+                        'chunk_groups': extra.get('chunks')})
+        if is_align or wname == 'api_align_signal':
             cfg.update({'reads_redone_exact': stats['reads_redone_exact'],
                         # reads in which a path comparison fell inside the tie margin (include/nadavca_hip.h)
                         'reads_tie_ambiguous': stats['reads_tie_ambiguous']})
@@ -255,7 +275,7 @@ def main():
                'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1000.0 * dt / args.steps,
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
                'data': 'synthetic', 'config': cfg}
-        kname = 'align' if (is_align or is_api) else 'ell_hyp'
+        kname = 'align' if (is_align or wname == 'api_align_signal') else 'ell_hyp'
         ms, launches = timing[kname]
         per_kernel = {k: v[0] / max(v[1], 1) for k, v in timing.items() if v[1]}
         if launches and is_align:

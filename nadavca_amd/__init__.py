@@ -6,7 +6,7 @@ does not touch the GPU; every compute entry point goes through the HIP library
 (nadavca_amd/csrc/libnadavca_hip.so) and fails loudly if it or the device is missing.
 """
 from . import dtw  # noqa: F401
-from .estimate_snps import estimate_snps  # noqa: F401
+from .estimate_snps import estimate_snps, estimate_snps_batch  # noqa: F401
 from .align_signal import align_signal, align_signal_batch  # noqa: F401
 
-__all__ = ['align_signal', 'align_signal_batch', 'estimate_snps', 'dtw']
+__all__ = ['align_signal', 'align_signal_batch', 'estimate_snps', 'estimate_snps_batch', 'dtw']

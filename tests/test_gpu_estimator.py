@@ -128,3 +128,73 @@ def test_align_signal_batch_equals_the_per_read_workflow(km):
     for j, (read, (apx, rows)) in enumerate(per_read):
         assert np.array_equal(out.alignment_of(j), rows)
         assert np.array_equal(out.normalized_signal(j), read.normalized_signal)
+
+
+def test_device_resident_consensus_path_reproduces_estimate_probabilities(fx, km):
+    """The data path bench.py's cfg4_consensus workload times at N = 1 — log-likelihoods, scatter-add into the
+    per-position sums, posterior, all on device-resident buffers (no host round trip of the sums) — against
+    ``estimate_probabilities`` (pinned to the reference's Python by the consensus fixture above)."""
+    import torch
+    from nadavca_amd.estimator import ProbabilityEstimator
+    from nadavca_amd.genome import Genome
+    from nadavca_amd.device import (DeviceBatch, estimate_log_likelihoods_dev, consensus_accumulate_dev,
+                                    posterior_segments_dev)
+    cfg = dict(fx.config, tweak_signal_normalization=False)
+    est = ProbabilityEstimator(km, fx.aligner(), cfg)
+    reads = fx.reads()
+    want = est.estimate_probabilities(fx.genome, reads)
+    live, batch, _, _ = est._log_likelihood_batch(fx.genome, fx.reads())
+    dev = torch.device('cuda', km.context.device)
+    db = DeviceBatch(batch, dev)
+    ll, status = estimate_log_likelihoods_dev(db, est.bandwidth, est.min_event_length, km, est.model_wobbling)
+    up = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)
+    start = up([p.apx.reference_range[0] for p in live], np.int64)
+    rev = up([1 if p.apx.reverse_complement else 0 for p in live], np.int32)
+    acc, cov = consensus_accumulate_dev(km.context, db, ll, start, rev, status, est.normalization_event_length,
+                                        len(fx.genome))
+    groups = est.group_ranges([tuple(int(v) for v in p.apx.reference_range) for p in live])
+    seg = np.concatenate([[0], np.cumsum([e - s for s, e in groups])]).astype(np.int64)
+    pos = up(np.concatenate([np.arange(s, e) for s, e in groups]), np.int64)
+    refnum = up(Genome.to_numerical(fx.genome), np.int32)[pos]
+    post = posterior_segments_dev(km.context, acc[pos], refnum, up(seg, np.int64), km.get_k(), est.snp_prior).cpu().numpy()
+    assert len(want) == len(groups)
+    for g, c in enumerate(want):
+        assert (c.start, c.end) == groups[g]
+        assert np.array_equal(c.coverage, cov.cpu().numpy()[c.start:c.end])
+        assert np.max(np.abs(post[seg[g]:seg[g + 1]] - c.values)) < 1e-12
+
+
+@pytest.mark.parametrize('tweak', [True, False])
+def test_estimate_snps_batch_equals_the_per_read_workflow(km, tweak):
+    """``estimate_snps_batch`` (struct-of-arrays in, sums and signals device-resident) against ``estimate_snps``
+    (the reference-shaped workflow, pinned to the reference's Python by the fixtures above): consensus chunks
+    and per-read chunks, with and without the spline tweak."""
+    from nadavca_amd import synthetic, defaults
+    from nadavca_amd.align_signal import _load_config
+    from nadavca_amd.alignment import ApproximateAligner
+    from nadavca_amd.estimate_snps import estimate_snps, estimate_snps_batch
+    from nadavca_amd.readbatch import ReadBatch, BaseAlignmentBatch, SyntheticBatchAligner
+    model = synthetic.load_model_arrays()
+    genome = np.random.default_rng(41).integers(0, 4, 1500).astype(np.int32)
+    specs = [synthetic.make_read_spec(np.random.default_rng([42, i]), genome, model, i, length=160, spread=30,
+                                      substitution_rate=0.03) for i in range(30)]
+    bases = np.array(list('ACGT'))[genome]
+    cfg = dict(_load_config(defaults.CONFIG_FILE), tweak_signal_normalization=tweak)
+    aligner = synthetic.make_synthetic_aligner(ApproximateAligner, bases)
+    bms = [np.asarray(s['base_mapping'], dtype=np.int64).reshape(-1, 2) for s in specs]
+    ba = BaseAlignmentBatch(np.concatenate([b[:, 0] for b in bms]), np.concatenate([b[:, 1] for b in bms]),
+                            np.concatenate([[0], np.cumsum([len(b) for b in bms])]), [s['reverse'] for s in specs])
+    for independent in (False, True):
+        want = estimate_snps(None, synthetic.reads_from_specs(specs), reference=bases, config=cfg, kmer_model=km,
+                             independent=independent, aligner=aligner)
+        rb = ReadBatch.from_reads(synthetic.reads_from_specs(specs))
+        got = estimate_snps_batch(genome, rb, config=cfg, kmer_model=km, independent=independent,
+                                  aligner=SyntheticBatchAligner(genome, ba))
+        if independent:
+            assert len(got) == len(want) == 30
+            got = [got.chunk(j) for j in range(len(got))]
+        assert len(got) == len(want)
+        for g, w in zip(got, want):
+            assert (g.start, g.end) == (w.start, w.end)
+            assert np.array_equal(g.coverage, w.coverage)
+            assert np.max(np.abs(g.values - w.values)) < 1e-9
