@@ -198,3 +198,98 @@ def test_estimate_snps_batch_equals_the_per_read_workflow(km, tweak):
             assert (g.start, g.end) == (w.start, w.end)
             assert np.array_equal(g.coverage, w.coverage)
             assert np.max(np.abs(g.values - w.values)) < 1e-9
+
+
+def _simulated(n, seed, **kw):
+    from nadavca_amd import synthetic
+    model = synthetic.load_model_arrays()
+    genome = np.random.default_rng(seed).integers(0, 4, 3000).astype(np.int32)
+    specs = [synthetic.make_read_spec(np.random.default_rng([seed + 1, i]), genome, model, i, length=200,
+                                      spread=30, **kw) for i in range(n)]
+    return genome, np.array(list('ACGT'))[genome], specs
+
+
+def test_cigar_anchor_stage_feeds_the_kernels(km):
+    """§8 f3: the approximate-alignment stage as the reference runs it — aligner hit (CIGAR, strand, position)
+    -> matched bases -> anchors -> signal window (alignment.py:62-186) — in front of the GPU refinement.  BWA
+    itself is replaced by a stub that reports each simulated read's true hit as a CIGAR string; everything
+    after ``_bwa_hit`` is the package's own code, and the refined alignments must equal those obtained from
+    the simulated base mapping directly."""
+    from nadavca_amd import synthetic
+    from nadavca_amd.alignment import ApproximateAligner
+    from nadavca_amd.estimator import ProbabilityEstimator
+    from nadavca_amd.read import Read
+    genome, bases, specs = _simulated(24, 31, substitution_rate=0.06)
+
+    class CigarAligner(ApproximateAligner):
+        def __init__(self, reference):
+            self.reference, self.references_dict, self.bwapy_aligner = reference, None, None
+
+        def _bwa_hit(self, read):
+            s = read._spec
+            if s is specs[5]:
+                return None                                        # an unmapped read
+            clip = 30 if s is specs[2] else 0                       # one hit with soft-clipped ends
+            cigar = '%dM' % s['length'] if not clip else '%dS%dM%dS' % (clip, s['length'] - 2 * clip, clip)
+            return cigar, s['reverse'], s['g0'] + clip, 'synthetic'
+
+    from nadavca_amd.align_signal import _load_config
+    from nadavca_amd import defaults
+    config = dict(_load_config(defaults.CONFIG_FILE), tweak_signal_normalization=False)
+    reads_a, reads_b = synthetic.reads_from_specs(specs), synthetic.reads_from_specs(specs)
+    Read.normalize_reads_device(reads_a, context=km.context)
+    Read.normalize_reads_device(reads_b, context=km.context)
+    via_cigar = ProbabilityEstimator(km, CigarAligner(bases), config).get_refined_alignments(reads_a)
+    direct = ProbabilityEstimator(km, synthetic.make_synthetic_aligner(ApproximateAligner, bases),
+                                  config).get_refined_alignments(reads_b)
+    assert via_cigar[5] is None and direct[5] is not None
+    same = 0
+    for j, (a, b) in enumerate(zip(via_cigar, direct)):
+        if j in (2, 5):
+            continue
+        assert a[0].reference_range == b[0].reference_range and a[0].reverse_complement == b[0].reverse_complement
+        assert np.array_equal(a[1], b[1])
+        same += 1
+    assert same == 22
+    # the clipped hit covers a shorter reference range, inside the unclipped one
+    (lo, hi), (LO, HI) = via_cigar[2][0].reference_range, direct[2][0].reference_range
+    assert LO <= lo < hi <= HI and hi - lo < HI - LO
+    assert via_cigar[2][1][0][0] == lo and via_cigar[2][1][-1][0] == hi - 1
+
+
+def test_detect_meth_rows(km, tmp_path):
+    """§8 f4: ``detect_meth`` = align_signal's renormalisation loop on the GPU + per-event scores; the CSV rows
+    against the same scores computed event by event from align_signal's own output."""
+    import csv
+    from scipy.stats import norm
+    from nadavca_amd import synthetic
+    from nadavca_amd.alignment import ApproximateAligner
+    from nadavca_amd.align_signal import align_signal
+    from nadavca_amd.detect_meth import detect_meth
+    from nadavca_amd.genome import Genome
+    _, bases, specs = _simulated(6, 41)
+    aligner = synthetic.make_synthetic_aligner(ApproximateAligner, bases)
+    out = tmp_path / 'meth.csv'
+    detect_meth(None, synthetic.reads_from_specs(specs), 'CG', str(out), kmer_model=km, aligner=aligner)
+    with open(out, newline='') as f:
+        rows = list(csv.reader(f))
+    assert rows[0] == ['Filename', 'Position', 'Sequence context', 'Position scores', 'Aggregated score']
+    want = []
+    for i, (read, (apx, al)) in enumerate(align_signal(None, synthetic.reads_from_specs(specs), kmer_model=km,
+                                                       aligner=aligner)):
+        seq = ''.join(apx.reference_part)
+        exp = km.get_expected_signal(Genome.to_numerical(apx.reference_part), [], [])
+        pos = seq.find('CG')
+        while pos != -1:
+            if pos >= 5 and pos + 6 <= len(al) and all(al[p][2] > al[p][1] for p in range(pos - 5, pos + 6)):
+                sc = [-np.log(max(1e-50, 2 * norm.cdf(-abs(np.mean(read.normalized_signal[al[p][1]:al[p][2]])
+                                                            - exp[p]) / 0.35287208)))
+                      for p in range(pos - 5, pos + 6)]
+                want.append(('read%d' % i, pos, seq[pos - 5:pos + 6], sc))
+            pos = seq.find('CG', pos + 1)
+    assert len(rows) - 1 == len(want) > 20
+    for row, (name, pos, ctx, sc) in zip(rows[1:], want):
+        assert row[0] == name and int(row[1]) == pos and row[2] == ctx
+        got = np.array(row[3].split(','), dtype=float)
+        assert np.allclose(got, sc, rtol=1e-12, atol=0)
+        assert float(row[4]) == pytest.approx(max(sum(sc[i:i + 3]) for i in range(9)), rel=1e-12)
