@@ -40,9 +40,11 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-# FP64 vector issue peak, measured (tools/ubench_valu.hip, profiles/ubench_valu_gfx950.txt): one v_fma_f64
-# wave-instruction per 2.24 ns and SIMD with 8 waves per SIMD; 1024 SIMDs x 64 lanes
-VALU_PEAK_TLANE = 1024 * 64 / 2.24e-9 / 1e12
+# vector-instruction issue peak: one wave64 VALU instruction per 4 cycles and SIMD at the 2.4 GHz maximum clock
+# (MI355X_MICROARCH.md), 1024 SIMDs x 64 lanes.  (tools/ubench_valu.hip measures 2.24 ns = ~5 cycles for
+# back-to-back dependent-free v_fma_f64 — the kernel's mix holds cheaper instructions too, so the 4-cycle
+# bound is the one no mix can exceed.)
+VALU_PEAK_TLANE = 1024 * 64 * 2.4e9 / 4 / 1e12
 
 
 def cpu_baseline(batch, model, bandwidth, mel, workload, budget_reads_per_core=256):
@@ -120,7 +122,7 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
+    if world > 1 or 'TORCHELASTIC_RUN_ID' in os.environ:   # under torch.distributed.run: also with one rank
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         torch.cuda.set_device(local_rank)
@@ -300,8 +302,9 @@ def main():
             traffic, _ = profile_figure('cfg3_snps', 'hbm_bytes_per_read')
             algo = dbatch.algorithmic_bytes_snp(stats['band_cells'])
             rl = {'bound': 'valu', 'kernel': kname, 'unit': 'TFLOP/s', 'peak': VALU_PEAK_TLANE,
-                  'note': 'FP64 vector lane-instructions per second (an FMA counts once); peak = measured '
-                          'v_fma_f64 issue rate x 1024 SIMDs x 64 lanes', 'from_profile': src,
+                  'note': 'vector lane-instructions per second, in units of 1e12 (an FMA counts once, so these '
+                          'are not flops); peak = 1 wave64 instruction / 4 cycles / SIMD at 2.4 GHz x 1024 SIMDs '
+                          'x 64 lanes', 'from_profile': src,
                   'kernel_ms_per_launch': ms / launches, 'all_kernels_ms': per_kernel,
                   'traffic': traffic * n_reads if traffic else None, 'algorithmic_bytes_per_launch': algo,
                   'hbm_frac': algo / sec / 1e9 / HBM_PEAK_GBS}

@@ -81,7 +81,10 @@ using dens::DensHalf;
 using dens::ETN;
 
 constexpr int CH = 64;      // signal refill chunk (samples)
-constexpr int PF = 8;       // forward sweep: spill prefetch depth (steps) = steps per loop trip
+#ifndef NVK_PF
+#define NVK_PF 8
+#endif
+constexpr int PF = NVK_PF;       // forward sweep: spill prefetch depth (steps) = steps per loop trip
 // rescale period: 2^rsh steps (launch parameter, >= 16); must exceed c + mel so that at most one
 // rescale lies inside the window a neighbour value travels through
 constexpr int GBIG = 1 << 24;  // scale of an empty running maximum (see the path step)
