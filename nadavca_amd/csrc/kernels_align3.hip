@@ -128,6 +128,20 @@ __device__ __forceinline__ double2 spill_load2(__amdgpu_buffer_rsrc_t rs, int la
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); \
     __builtin_amdgcn_wave_barrier();                       \
   } while (0)
+// end of a step: the history ring's writes of this step before the next step's reads.  A team of waves
+// (W > 1) meets at a workgroup barrier behind a wait for its LDS operations ONLY — __syncthreads() would
+// also wait for the spill stores / the spill prefetch in flight, which is the traffic the step overlaps.
+#define STEP_SYNC()                                                              \
+  do {                                                                           \
+    if (W == 1) WAVE_SYNC();                                                     \
+    else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");         \
+  } while (0)
+// around a refill of the wave's own signal ring (inside wave-uniform, not team-uniform, control flow)
+#define RING_SYNC()                 \
+  do {                              \
+    if (W == 1) __syncthreads();    \
+    else WAVE_SYNC();               \
+  } while (0)
 
 // What one lane needs to sweep one row, per sweep direction: the density of the step it applies
 // (forward: r-1 -> r, reverse: r -> r+1) with ac/mc pre-scaled for density(), its own span and the
@@ -204,13 +218,14 @@ __global__ __launch_bounds__(256) void lane3_kernel(const ReadMeta *metas, const
   if (m.status != NVK_READ_OK) return;
   const RowParam *rw = rows + m.row_off;
   const int T = m.T, N = m.N, top = T - 1;
+  const int ST = m.cw ? 64 * ALIGN3_TEAM_W : 64;  // rows between a lane's consecutive rows
   for (int r = threadIdx.x; r < T; r += blockDim.x) {
     const RowParam o = rw[r];
     Lane3 f, b;
     // forward: applies step r-1 -> r
     f.bs = o.bs; f.end = o.be; f.lo = o.lo;
-    const int adv_f = (r >= 64) ? o.off - rw[r - 64].off : 0;
-    const int adv_b = (r + 64 <= top) ? rw[r + 64].off - o.off : 0;
+    const int adv_f = (r >= ST) ? o.off - rw[r - ST].off : 0;
+    const int adv_b = (r + ST <= top) ? rw[r + ST].off - o.off : 0;
     if (r > 0) {
       const RowParam p = rw[r - 1];
       set_density_consts(f, p);
@@ -253,7 +268,7 @@ __global__ __launch_bounds__(256) void lane3_kernel(const ReadMeta *metas, const
     melr = (l).mg & 15;                                                                \
     D = ((l).mg >> 4) & 255;                                                           \
     bs = (l).bs; pA = (l).pA; pW = (l).pW;                                             \
-    ra = (int)min((unsigned)(su - D), (unsigned)(su - D + H)) * 64 + nb;               \
+    ra = (int)min((unsigned)(su - D), (unsigned)(su - D + H)) * TL + nb;               \
     if (!PAIR) { pm = melr ? 1.0 : 0.0; qm = melr ? 0.0 : 1.0; }                       \
     if (PAIR && !em) cq = (shift_now != 0) ? ldexp((l).mean, shift_now) : (l).mean;    \
   } while (0)
@@ -331,28 +346,47 @@ struct Scale {
 #ifndef NVK_LB_REV
 #define NVK_LB_REV 7
 #endif
-template <int MEL, int RSHC, bool PAIR, int PHASE>
-__global__ __launch_bounds__(64, PHASE == 1 ? NVK_LB_REV : NVK_LB) void align3_kernel(Align3Args g) {
+#define NVK_LB_REV_TEAM 6  // (the team's reverse sweep needs 76 registers: 80 without spills)
+//
+// W: waves per read.  1 — the mapping above.  W > 1 (wide bands: ReadMeta::cw != 0, two-launch form only) — a
+// TEAM of W waves sweeps one read with one row per lane of its TL = 64 W lanes: a lane's next row lies TL
+// rows on, so the skew a band of given width needs falls roughly W-fold (and with it the history ring per
+// lane, i.e. LDS per wave: BASELINE config 5 reads need skew ~28 and 57 KB of LDS with one wave — 2 waves
+// per CU — and skew 3 and 10 KB per wave with four).  The history ring is shared by the team ([slot][team
+// lane]; the value of lane 63 of one wave goes to lane 0 of the next), everything else stays per wave: its
+// own signal ring and refill bookkeeping, its own spill region and bit words, its own row switches.  The
+// team moves in lockstep — one workgroup barrier per step (STEP_SYNC) — and shares ONE running scale:
+// every wave posts its largest exponent one step before the rescale step and all take the maximum.  The
+// ring has one slot more than the oldest age read (c + mel + 1): within one wave "read the oldest slot,
+// then overwrite it" is program order, across waves it would be a race.
+template <int MEL, int RSHC, bool PAIR, int PHASE, int W>
+__global__ __launch_bounds__(64 * W, PHASE == 1 ? (W > 1 ? NVK_LB_REV_TEAM : NVK_LB_REV) : NVK_LB) void align3_kernel(Align3Args g) {
+  static_assert(W == 1 || PHASE != 0, "teams exist in the two-launch form only");
+  constexpr int TL = 64 * W;  // lanes of the team
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int gl = threadIdx.x;  // lane of the team
+  const int wv = (W > 1) ? __builtin_amdgcn_readfirstlane(gl >> 6) : 0;
   double *etab = reinterpret_cast<double *>(smem);
-  double *ring = etab + ETN;
-  double *hist = ring + g.SR;                                   // reverse sweep: suffix values
-  double2 *hist2 = reinterpret_cast<double2 *>(ring + g.SR);   // forward sweep: (prefix, path score)
+  double *ring = etab + ETN + (size_t)wv * g.SR;               // the wave's own signal ring
+  double *hist = etab + ETN + (size_t)W * g.SR;                 // reverse sweep: suffix values
+  double2 *hist2 = reinterpret_cast<double2 *>(hist);          // forward sweep: (prefix, path score)
   // entry H*64 of both arrays is a permanent zero: a lane whose predecessor cell lies outside the
   // predecessor's band reads it instead of masking what it read (one select on the index instead of
   // one per loaded register)
   // (the reverse-only launch keeps 8 bytes per lane and slot: its zero entry is hist[H*64])
-  int *ghist = reinterpret_cast<int *>(hist2 + (size_t)g.H * 64 + 1);
-  int *s_read = (PHASE == 1) ? reinterpret_cast<int *>(hist + (size_t)g.H * 64 + 1) : ghist + (size_t)g.H * 64 + 1;
+  int *ghist = reinterpret_cast<int *>(hist2 + (size_t)g.H * TL + 1);
+  int *s_read = (PHASE == 1) ? reinterpret_cast<int *>(hist + (size_t)g.H * TL + 1) : ghist + (size_t)g.H * TL + 1;
+  // team exchange: every wave's largest exponent (rescale), its flags, and the last row's arg-max
+  int *tmax = s_read + 2, *tflag = tmax + W, *tfidx = tflag + W;
 
-  const int lane = threadIdx.x;
+  const int lane = gl & 63;
   const int H = g.H, RM = g.SR - 1;
   uint32_t *bp = g.bp + (size_t)blockIdx.x * g.bp_stride;
 
-  for (int q = lane; q < g.SR; q += 64) ring[q] = 0.0;
-  dens::fill_table(etab, lane, 64);
-  const int HZ = H * 64;
-  if (lane == 0) {
+  for (int q = gl; q < W * g.SR; q += TL) etab[ETN + q] = 0.0;
+  dens::fill_table(etab, gl, TL);
+  const int HZ = H * TL;
+  if (gl == 0) {
     if (PHASE == 1) {
       hist[HZ] = 0.0;
     } else {
@@ -365,12 +399,13 @@ __global__ __launch_bounds__(64, PHASE == 1 ? NVK_LB_REV : NVK_LB) void align3_k
   // the indices of the zero entry
   unsigned char *histb = reinterpret_cast<unsigned char *>(hist2);
   unsigned char *ghistb = reinterpret_cast<unsigned char *>(ghist);
-  int lane16 = lane * 16, lane8 = lane * 8, HZv = HZ, HZ2v = (PHASE == 1) ? HZ : 2 * HZ;
-  asm volatile("" : "+v"(lane16), "+v"(lane8), "+v"(HZv), "+v"(HZ2v));
+  int gl16 = gl * 16, gl8 = gl * 8, HZv = HZ, HZ2v = (PHASE == 1) ? HZ : 2 * HZ;
+  asm volatile("" : "+v"(gl16), "+v"(gl8), "+v"(HZv), "+v"(HZ2v));
+  const int lane16 = (W == 1) ? gl16 : lane * 16;  // the lane's offset inside a step of the wave's spill
 
   while (true) {
     __syncthreads();
-    if (lane == 0) *s_read = atomicAdd(g.counter, 1);
+    if (gl == 0) *s_read = atomicAdd(g.counter, 1);
     __syncthreads();
     const int pos0 = __builtin_amdgcn_readfirstlane(*s_read);
     if (pos0 >= g.n_reads) break;
@@ -378,12 +413,13 @@ __global__ __launch_bounds__(64, PHASE == 1 ? NVK_LB_REV : NVK_LB) void align3_k
     const int rd = g.order ? g.order[pos] : pos;
     const ReadMeta m = g.metas[rd];
     if (m.status != NVK_READ_OK) {
-      if (PHASE != 1 && lane == 0) g.out_status[rd] = m.status;
+      if (PHASE != 1 && gl == 0) g.out_status[rd] = m.status;
       continue;
     }
-    if (m.c <= g.c_lo) continue;  // served by the launch with the smaller rings
-    if (m.c > g.c_cap) {           // band too wide for this launch's LDS rings
-      if (PHASE != 1 && g.flag_above && lane == 0) {
+    if ((W > 1) != (m.cw != 0)) continue;  // served by the other launch (one wave per read / a team)
+    const int cm = (W > 1) ? m.cw : m.c;
+    if (cm > g.c_cap) {           // band too wide for this launch's LDS rings
+      if (PHASE != 1 && g.flag_above && gl == 0) {
         g.out_status[rd] = NVK_READ_RETRY_INTERNAL;
         atomicAdd(g.n_retry, 1);
       }
@@ -394,11 +430,11 @@ __global__ __launch_bounds__(64, PHASE == 1 ? NVK_LB_REV : NVK_LB) void align3_k
     // bounds every offset by construction)
     const size_t slot = (PHASE == 0) ? (size_t)blockIdx.x : (size_t)pos0;
     const __amdgpu_buffer_rsrc_t spill_rs = __builtin_amdgcn_make_buffer_rsrc(
-        g.spill_v + slot * g.spill_stride, 0, 0x7ffffff0, 0x00020000);
+        g.spill_v + (slot * W + wv) * g.spill_stride, 0, 0x7ffffff0, 0x00020000);
     int32_t *spill_L = g.spill_L + slot * g.L_stride;
     const int T = __builtin_amdgcn_readfirstlane(m.T);
     const int N = __builtin_amdgcn_readfirstlane(m.N);
-    const int c = __builtin_amdgcn_readfirstlane(m.c);
+    const int c = __builtin_amdgcn_readfirstlane(cm);
     const int t_min = __builtin_amdgcn_readfirstlane(m.t_min);
     const int n_steps = __builtin_amdgcn_readfirstlane(m.pad);  // steps under the per-row offsets
     const int t_max = t_min + n_steps - 1;
@@ -416,7 +452,7 @@ __global__ __launch_bounds__(64, PHASE == 1 ? NVK_LB_REV : NVK_LB) void align3_k
 
     // =========================== reverse sweep: suffix rows -> spill ===========================
     if (PHASE != 2) {
-      int r = top - ((top - lane) & 63);
+      int r = top - ((top - gl) & (TL - 1));
       // Lanes without a row keep bs = hi = -big: never active, never finished.  For the other
       // rows `hi` already folds the "predecessor column exists" test (i + mel <= N).
       double mean = 0, ac2 = 0, mc2 = 0;
@@ -430,8 +466,8 @@ __global__ __launch_bounds__(64, PHASE == 1 ? NVK_LB_REV : NVK_LB) void align3_k
       int shift_now = 0; // scale move of the current step (uniform)
       if (PAIR) { pm = em ? 1.0 : 0.0; qm = em ? 0.0 : 1.0; }
       int su = 0;                       // history slot written at this step
-      const int nb = (lane + 1) & 63;   // the lane the values come from
-      int ra = (H - 1) * 64 + nb;       // read index into the history ring, advanced with su
+      const int nb = (gl + 1) & (TL - 1);   // the lane the values come from
+      int ra = (H - 1) * TL + nb;       // read index into the history ring, advanced with su
       bool is_init = false;
       int i = t_max;
       if (r >= 0) {
@@ -444,8 +480,8 @@ __global__ __launch_bounds__(64, PHASE == 1 ? NVK_LB_REV : NVK_LB) void align3_k
       double prev = 0.0, e1 = 1.0, e2 = 1.0, e3 = 1.0;
       double o_hold = 0.0;  // the value of the even step of a trip, stored together with the odd step's
       int kmax = -0x40000000;
-      int r_old = top;
-      int i_old = __builtin_amdgcn_readlane(i, top & 63);  // sample index of the oldest open row (scalar)
+      int r_old = (W == 1) ? top : max(wave_max_i(r), -1);  // the oldest open row of this wave
+      int i_old = __builtin_amdgcn_readlane(i, r_old & 63);  // sample index of the oldest open row (scalar)
       int filled_lo = (i_old / CH + 1) * CH;
       while (i_old - 3 < filled_lo) {
         filled_lo -= CH;
@@ -497,7 +533,7 @@ __global__ __launch_bounds__(64, PHASE == 1 ? NVK_LB_REV : NVK_LB) void align3_k
           bool redo = false;  // this lane must re-evaluate the density its `e` stands for
           for (unsigned long long fm = __builtin_amdgcn_ballot_w64(fin); fm != 0; fm &= fm - 1) {
             const int fl = __builtin_ctzll(fm);
-            const int rn = __builtin_amdgcn_readlane(r, fl) - 64;  // (uniform) the row that lane takes
+            const int rn = __builtin_amdgcn_readlane(r, fl) - TL;  // (uniform) the row that lane takes
             Lane3 nx;
             nx.mean = nx.ac = nx.mc = 0.0; nx.bs = nx.end = nx.lo = nx.pA = nx.pW = nx.mg = 0;
             if (rn >= 0) nx = lane3_sload(revl + rn);
@@ -534,7 +570,8 @@ __global__ __launch_bounds__(64, PHASE == 1 ? NVK_LB_REV : NVK_LB) void align3_k
           } else if (redo) {
             e = density(ring[i & RM], mean, ac2, mc2, shift_now, etab);
           }
-          while (r_old >= 0 && __builtin_amdgcn_readlane(r, r_old & 63) != r_old) r_old--;
+          while (r_old >= 0 && __builtin_amdgcn_readlane(r, r_old & 63) != r_old)
+            r_old -= (W > 1 && (r_old & 63) == 0) ? 1 + 64 * (W - 1) : 1;  // (the wave's rows only)
           i_old = __builtin_amdgcn_readlane(i, r_old & 63);
           init_live &= (__builtin_amdgcn_readlane(r, top & 63) == top) ? 1 : 0;
           row0_live = (__builtin_amdgcn_readfirstlane(r) == 0) ? 1 : 0;
@@ -545,12 +582,12 @@ __global__ __launch_bounds__(64, PHASE == 1 ? NVK_LB_REV : NVK_LB) void align3_k
           const int need_min = i_old - (PAIR ? 3 : 2);
           while (need_min < filled_lo) {
             filled_lo -= CH;
-            __syncthreads();
+            RING_SYNC();
             for (int q = lane; q < CH; q += 64) {
               int idx = filled_lo + q;
               ring[idx & RM] = (idx >= 0 && idx < N) ? sig[idx] : 0.0;
             }
-            __syncthreads();
+            RING_SYNC();
           }
         }
 #if NVK_PAIR_DEBUG == 2
@@ -610,9 +647,9 @@ __global__ __launch_bounds__(64, PHASE == 1 ? NVK_LB_REV : NVK_LB) void align3_k
           if (o != 0.0) kmax = max(kmax, __builtin_amdgcn_frexp_exp(o) - sc.L);
         }
 #if NVK_ABL == 10
-        if (!(uq & 1)) *reinterpret_cast<double *>(histb + (su * 512 + lane8)) = o;
+        if (!(uq & 1)) *reinterpret_cast<double *>(histb + (su * (8 * TL) + gl8)) = o;
 #elif NVK_ABL != 7
-        *reinterpret_cast<double *>(histb + (su * 512 + lane8)) = o;
+        *reinterpret_cast<double *>(histb + (su * (8 * TL) + gl8)) = o;
 #endif
         // (n_steps is even: an odd u is the even step 2p of the forward order, the step before it 2p + 1)
         if (uq & 1) {
@@ -624,15 +661,26 @@ __global__ __launch_bounds__(64, PHASE == 1 ? NVK_LB_REV : NVK_LB) void align3_k
         }
         if (age == 0) {  // the scale only moves on these steps
           asm volatile("");  // (a scalar branch first: the lane test need not run at every step)
-          if (lane == 0) spill_L[u >> RSH] = sc.L;
+          if (gl == 0) spill_L[u >> RSH] = sc.L;
         }
         // ---- rescale decision for the next step, then the next step's density
+        if (W > 1 && age == RS - 2) {  // team: the waves' largest exponents meet one step ahead
+          const int mxw = wave_max_i((o != 0.0) ? __builtin_amdgcn_frexp_exp(o) : -0x40000000);
+          if (lane == 0) tmax[wv] = mxw;
+        }
         if (age == RS - 1) {
           // (range guard of the values themselves: here only — an inf or NaN between two rescale steps
           // reaches the posterior sums of its row and fails the row-mass check)
           suspect |= !(o <= HUGE_V);
-          int ex = (o != 0.0) ? __builtin_amdgcn_frexp_exp(o) : -0x40000000;
-          int mx = wave_max_i(ex);
+          int mx;
+          if (W == 1) {
+            mx = wave_max_i((o != 0.0) ? __builtin_amdgcn_frexp_exp(o) : -0x40000000);
+          } else {
+            mx = tmax[0];
+#pragma unroll
+            for (int w = 1; w < W; w++) mx = max(mx, tmax[w]);
+            mx = __builtin_amdgcn_readfirstlane(mx);
+          }
           sc.d_next = (mx > -0x40000000) ? min(TARGET - mx, DMAX) : 0;
           suspect |= (mx > -0x40000000) && (TARGET - mx > DMAX);
 #ifdef NVK_FLAG_DEBUG
@@ -653,11 +701,11 @@ __global__ __launch_bounds__(64, PHASE == 1 ? NVK_LB_REV : NVK_LB) void align3_k
           e = pair_swap(e);  // the emitting lane takes what its partner evaluated one step ago
         }
         su = (su + 1 == H) ? 0 : su + 1;
-        ra = (int)min((unsigned)(ra + 64), (unsigned)(ra + 64 - HZ));
+        ra = (int)min((unsigned)(ra + TL), (unsigned)(ra + TL - HZ));
 #if NVK_ABL == 10
-        if (uq & 1) WAVE_SYNC();
+        if (uq & 1) STEP_SYNC();
 #elif NVK_ABL != 2
-        WAVE_SYNC();
+        STEP_SYNC();
 #endif
       }
       }
@@ -665,8 +713,16 @@ __global__ __launch_bounds__(64, PHASE == 1 ? NVK_LB_REV : NVK_LB) void align3_k
       if (K == -0x40000000) K = 0;
     }
     if (PHASE == 1) {  // hand K and the range guard's verdict to the forward launch
-      const bool any_s = __any(suspect);
-      if (lane == 0) g.rstate[rd] = make_int2(K, any_s ? 1 : 0);
+      bool any_s = __any(suspect);
+      if (W > 1) {  // (row 0, and so K, lives in wave 0)
+        if (lane == 0) tflag[wv] = any_s ? 1 : 0;
+        __syncthreads();
+        int fl = 0;
+#pragma unroll
+        for (int w = 0; w < W; w++) fl |= tflag[w];
+        any_s = (fl != 0);
+      }
+      if (gl == 0) g.rstate[rd] = make_int2(K, any_s ? 1 : 0);
       continue;
     }
     if (PHASE == 2) {
@@ -684,7 +740,7 @@ __global__ __launch_bounds__(64, PHASE == 1 ? NVK_LB_REV : NVK_LB) void align3_k
     int fidx = -1, fG = 0;
     unsigned long long amb = 0;  // (scalar) lanes that saw a comparison inside the tolerance band
     {
-      int r = lane;
+      int r = gl;
       // Lanes without a row keep lo = be = +big: never active, never finished.  For the other rows
       // `lo` already folds the "predecessor column exists" test (i - mel >= 0).
       double mean = 0, ac2 = 0, mc2 = 0;
@@ -696,8 +752,8 @@ __global__ __launch_bounds__(64, PHASE == 1 ? NVK_LB_REV : NVK_LB) void align3_k
       int ia = 0, dsel = 0, shift_now = 0;  // see the reverse sweep
       if (PAIR) { pm = em ? 1.0 : 0.0; qm = em ? 0.0 : 1.0; }
       int su = 0;
-      const int nb = (lane - 1) & 63;
-      int ra = (H - 1) * 64 + nb;
+      const int nb = (gl - 1) & (TL - 1);
+      int ra = (H - 1) * TL + nb;
       bool is_init = false;
       int i = t_min - 64 * c;
       if (r < T) {
@@ -718,10 +774,11 @@ __global__ __launch_bounds__(64, PHASE == 1 ? NVK_LB_REV : NVK_LB) void align3_k
       // matters, some row's sum deviates — checked over all rows at the end of the read.
       double rsum = 0.0, smin = INFINITY, smax = 0.0;
       uint32_t bits = 0;
-      int r_old = 0;
-      int i_old = t_min;  // sample index of the oldest open row (scalar): offs[0] = 0
-      int filled_hi = ((t_min - MEL - 1) > 0 ? (t_min - MEL - 1) / CH : 0) * CH;
-      while (t_min + 2 >= filled_hi) {
+      int r_old = min(64 * wv, T);  // the oldest open row of this wave
+      // sample index of the oldest open row (scalar): t_min for row 0 (offs[0] = 0)
+      int i_old = (r_old < T) ? __builtin_amdgcn_readfirstlane(i) : t_min;
+      int filled_hi = ((i_old - MEL - 1) > 0 ? (i_old - MEL - 1) / CH : 0) * CH;
+      while (i_old + 2 >= filled_hi) {
         for (int w = lane; w < CH; w += 64) {
           int idx = filled_hi + w;
           ring[idx & RM] = (idx >= 0 && idx < N) ? sig[idx] : 0.0;
@@ -743,7 +800,7 @@ __global__ __launch_bounds__(64, PHASE == 1 ? NVK_LB_REV : NVK_LB) void align3_k
       double e = density(ring[ia & RM], mean, ac2, mc2, 0, etab);
       if (PAIR) ia = (em ? i : ip0 + 1) + 1;  // first evaluation at step 1
       int init_live = 1;  // (uniform, scalar registers) row 0 is still being swept
-      int top_live = (top < 64) ? 1 : 0;  // the last row has been started
+      int top_live = (top < TL) ? 1 : 0;  // the last row has been started
 
       double2 cur_v[PF / 2];
 #pragma unroll
@@ -778,7 +835,7 @@ __global__ __launch_bounds__(64, PHASE == 1 ? NVK_LB_REV : NVK_LB) void align3_k
               bool redo = false;
               for (unsigned long long fm = __builtin_amdgcn_ballot_w64(fin); fm != 0; fm &= fm - 1) {
                 const int fl = __builtin_ctzll(fm);
-                const int rn = __builtin_amdgcn_readlane(r, fl) + 64;  // (uniform) the row that lane takes
+                const int rn = __builtin_amdgcn_readlane(r, fl) + TL;  // (uniform) the row that lane takes
                 Lane3 nx;
                 nx.mean = nx.ac = nx.mc = 0.0; nx.bs = nx.end = nx.lo = nx.pA = nx.pW = nx.mg = 0;
                 if (rn < T) nx = lane3_sload(fwdl + rn);
@@ -814,7 +871,8 @@ __global__ __launch_bounds__(64, PHASE == 1 ? NVK_LB_REV : NVK_LB) void align3_k
               } else if (redo) {
                 e = density(ring[(i - 1) & RM], mean, ac2, mc2, shift_now, etab);
               }
-              while (r_old < T && __builtin_amdgcn_readlane(r, r_old & 63) != r_old) r_old++;
+              while (r_old < T && __builtin_amdgcn_readlane(r, r_old & 63) != r_old)
+                r_old += (W > 1 && (r_old & 63) == 63) ? 1 + 64 * (W - 1) : 1;  // (the wave's rows only)
               i_old = __builtin_amdgcn_readlane(i, r_old & 63);
               init_live &= (__builtin_amdgcn_readfirstlane(r) == 0) ? 1 : 0;
               top_live = (__builtin_amdgcn_readlane(r, top & 63) == top) ? 1 : 0;
@@ -822,13 +880,13 @@ __global__ __launch_bounds__(64, PHASE == 1 ? NVK_LB_REV : NVK_LB) void align3_k
             if (r_old < T) {
               const int need_max = i_old + (PAIR ? 2 : 1);  // (PAIR: the partner evaluates one sample further ahead)
               while (need_max >= filled_hi) {
-                __syncthreads();
+                RING_SYNC();
                 for (int w = lane; w < CH; w += 64) {
                   int idx = filled_hi + w;
                   ring[idx & RM] = (idx >= 0 && idx < N) ? sig[idx] : 0.0;
                 }
                 filled_hi += CH;
-                __syncthreads();
+                RING_SYNC();
               }
             }
 #if NVK_PAIR_DEBUG == 2
@@ -935,13 +993,13 @@ __global__ __launch_bounds__(64, PHASE == 1 ? NVK_LB_REV : NVK_LB) void align3_k
               }
             }
 #if NVK_ABL != 7
-            *reinterpret_cast<double2 *>(histb + (su * 1024 + lane16)) = make_double2(o, dpv);
-            *reinterpret_cast<int *>(ghistb + (su * 256 + (lane16 >> 2))) = Gd;
+            *reinterpret_cast<double2 *>(histb + (su * (16 * TL) + gl16)) = make_double2(o, dpv);
+            *reinterpret_cast<int *>(ghistb + (su * (4 * TL) + (gl16 >> 2))) = Gd;
 #endif
             if ((u & 31) == 31 || u == n_steps - 1) {
               int w = u >> 5;
               asm volatile("" : "+s"(w));  // keeps the address arithmetic inside the branch
-              bp[(size_t)w * 64 + lane] = bits << (31 - (u & 31));
+              bp[(size_t)w * TL + gl] = bits << (31 - (u & 31));
               bits = 0;
             }
             // refill the prefetch slot just consumed
@@ -949,10 +1007,21 @@ __global__ __launch_bounds__(64, PHASE == 1 ? NVK_LB_REV : NVK_LB) void align3_k
             if (q & 1) cur_v[q >> 1] = spill_load2(spill_rs, lane16, (u + PF) >> 1);
 #endif
             // ---- rescale decision for the next step, then the next step's density
+            if (W > 1 && age == RS - 2) {  // see the reverse sweep
+              const int mxw = wave_max_i((o != 0.0) ? __builtin_amdgcn_frexp_exp(o) : -0x40000000);
+              if (lane == 0) tmax[wv] = mxw;
+            }
             if (age == RS - 1) {
               suspect |= !(o <= HUGE_V);
-              int ex = (o != 0.0) ? __builtin_amdgcn_frexp_exp(o) : -0x40000000;
-              int mx = wave_max_i(ex);
+              int mx;
+              if (W == 1) {
+                mx = wave_max_i((o != 0.0) ? __builtin_amdgcn_frexp_exp(o) : -0x40000000);
+              } else {
+                mx = tmax[0];
+#pragma unroll
+                for (int w = 1; w < W; w++) mx = max(mx, tmax[w]);
+                mx = __builtin_amdgcn_readfirstlane(mx);
+              }
               sc.d_next = (mx > -0x40000000) ? min(TARGET - mx, DMAX) : 0;
               suspect |= (mx > -0x40000000) && (TARGET - mx > DMAX);
 #ifdef NVK_FLAG_DEBUG
@@ -973,9 +1042,9 @@ __global__ __launch_bounds__(64, PHASE == 1 ? NVK_LB_REV : NVK_LB) void align3_k
               e = pair_swap(e);
             }
             su = (su + 1 == H) ? 0 : su + 1;
-            ra = (int)min((unsigned)(ra + 64), (unsigned)(ra + 64 - HZ));
+            ra = (int)min((unsigned)(ra + TL), (unsigned)(ra + TL - HZ));
 #if NVK_ABL != 2
-            WAVE_SYNC();
+            STEP_SYNC();
 #endif
           }
         }
@@ -998,21 +1067,32 @@ __global__ __launch_bounds__(64, PHASE == 1 ? NVK_LB_REV : NVK_LB) void align3_k
 
     // ====================================== traceback ============================================
     int idx = __shfl(fidx, top & 63, 64);
-    const bool any_suspect = __any(suspect);
+    bool any_suspect = __any(suspect);
+    if (W > 1) {  // the team's verdict: any wave's range guard or tie flag, the arg-max of the wave that held `top`
+      if (lane == 0) tflag[wv] = (any_suspect ? 1 : 0) | (amb != 0 ? 2 : 0);
+      if (gl == (top & (TL - 1))) *tfidx = fidx;
+      __syncthreads();
+      int fl = 0;
+#pragma unroll
+      for (int w = 0; w < W; w++) fl |= tflag[w];
+      any_suspect = (fl & 1) != 0;
+      amb = (fl & 2) ? 1ull : 0ull;
+      idx = *tfidx;
+    }
     if (any_suspect || (idx < 0 && K != 0)) {
       // out of range somewhere, or no path although the suffix sweep found mass: exact kernel
-      if (lane == 0) {
+      if (gl == 0) {
         g.out_status[rd] = NVK_READ_RETRY_INTERNAL;
         atomicAdd(g.n_retry, 1);
       }
       continue;
     }
     if (idx < 0) {
-      if (lane == 0) g.out_status[rd] = NVK_READ_NO_PATH;
+      if (gl == 0) g.out_status[rd] = NVK_READ_NO_PATH;
       continue;
     }
-    if (lane == 0 && amb != 0) g.ties[rd] = 1;
-    if (lane == 0) {
+    if (gl == 0 && amb != 0) g.ties[rd] = 1;
+    if (gl == 0) {
       int32_t *ev = g.out_events + 2 * m.ref_off;
       int st = NVK_READ_OK;
       int off_r = offs[top];
@@ -1029,10 +1109,10 @@ __global__ __launch_bounds__(64, PHASE == 1 ? NVK_LB_REV : NVK_LB) void align3_k
         const int pm = g.transitions ? ((r - 1) & 1 ? 0 : MEL) : MEL;
         int u = idx + off_c - t_min;
         int w = u >> 5;
-        uint32_t v = bp[(size_t)w * 64 + (r & 63)] & (0xffffffffu << (31 - (u & 31)));
+        uint32_t v = bp[(size_t)w * TL + (r & (TL - 1))] & (0xffffffffu << (31 - (u & 31)));
         while (v == 0 && w > 0) {
           --w;
-          v = bp[(size_t)w * 64 + (r & 63)];
+          v = bp[(size_t)w * TL + (r & (TL - 1))];
         }
         if (v == 0) {
           st = NVK_READ_RETRY_INTERNAL;
@@ -1095,15 +1175,17 @@ int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadM
 #endif
   void (*k16[3])(Align3Args) = {nullptr, nullptr, nullptr};
   void (*kv[3])(Align3Args) = {nullptr, nullptr, nullptr};
+  void (*kt[3])(Align3Args) = {nullptr, nullptr, nullptr};  // teams of ALIGN3_TEAM_W waves (wide bands)
 #if NVK_TWO_PHASE
 #define A3_SET(M, P)                                                                           \
   do {                                                                                         \
-    k16[1] = align3_kernel<M, 4, P, 1>; k16[2] = align3_kernel<M, 4, P, 2>;                    \
-    kv[1] = align3_kernel<M, 0, P, 1>; kv[2] = align3_kernel<M, 0, P, 2>;                      \
+    k16[1] = align3_kernel<M, 4, P, 1, 1>; k16[2] = align3_kernel<M, 4, P, 2, 1>;              \
+    kv[1] = align3_kernel<M, 0, P, 1, 1>; kv[2] = align3_kernel<M, 0, P, 2, 1>;                \
+    kt[1] = align3_kernel<M, 0, P, 1, ALIGN3_TEAM_W>; kt[2] = align3_kernel<M, 0, P, 2, ALIGN3_TEAM_W>; \
   } while (0)
 #else
 #define A3_SET(M, P)                                                                           \
-  do { k16[0] = align3_kernel<M, 4, P, 0>; kv[0] = align3_kernel<M, 0, P, 0>; } while (0)
+  do { k16[0] = align3_kernel<M, 4, P, 0, 1>; kv[0] = align3_kernel<M, 0, P, 0, 1>; } while (0)
 #endif
 #define A3_PICK(M)                                                                             \
   do {                                                                                         \
@@ -1132,14 +1214,17 @@ int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadM
   // Two launches: the LDS rings are sized by the largest skew a launch serves, so the (usual) reads
   // with c <= ALIGN1_C_CAP keep their 16 waves per CU whatever else is in the batch; wide-band reads
   // (long reads, BASELINE config 5) run with larger rings and a longer rescale period.
-  const int C_HARD = 58;  // rescale period 64 must exceed c + mel
-  struct Cls { int lo, hi; int64_t reads; };
+  // (wide bands: teams of ALIGN3_TEAM_W waves, ReadMeta::cw; their history ring of (cw + mel + 1) slots of
+  // 256 lanes x 20 B has to fit the 160 KB of a CU)
+  const int C_HARD = 24;
+  struct Cls { int lo, hi; int64_t reads; int W; };
   Cls cls[2];
   int ncls = 0;
   const int64_t n_wide = (int64_t)tot.n_wide;
+  const int max_cw = tot.max_cw < 1 ? 1 : tot.max_cw;
   if (a.n_reads - n_wide > 0 || max_c <= ALIGN1_C_CAP)
-    cls[ncls++] = Cls{0, max_c < ALIGN1_C_CAP ? max_c : ALIGN1_C_CAP, a.n_reads - n_wide};
-  if (max_c > ALIGN1_C_CAP) cls[ncls++] = Cls{ALIGN1_C_CAP, max_c < C_HARD ? max_c : C_HARD, n_wide};
+    cls[ncls++] = Cls{0, max_c < ALIGN1_C_CAP ? max_c : ALIGN1_C_CAP, a.n_reads - n_wide, 1};
+  if (max_c > ALIGN1_C_CAP) cls[ncls++] = Cls{0, max_cw < C_HARD ? max_cw : C_HARD, n_wide, ALIGN3_TEAM_W};
 #if NVK_TWO_PHASE
   // steps of the reads in launch order (longest first, bucket by bucket): sizes the per-read spill slots
   std::vector<int32_t> steps_sorted;
@@ -1162,7 +1247,16 @@ int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadM
 #endif
   TimerScope ts_align(ctx, NVK_K_ALIGN);
   for (int k = 0; k < ncls; k++) {
-    const int c = cls[k].hi;
+    int c = cls[k].hi;
+    const int W = cls[k].W, TLk = 64 * W;
+    // the widest skew whose rings fit a CU's LDS (reads beyond it go to the exact kernel)
+    auto lds_need = [&](int cc, int slot_bytes) {
+      const int Hc = (cc + mel > 0 ? cc + mel : 1) + (W > 1 ? 1 : 0);
+      int SRc = 256;
+      while (SRc < 64 * cc + CH) SRc <<= 1;
+      return (size_t)ETN * 8 + (size_t)W * SRc * 8 + (size_t)Hc * TLk * slot_bytes + slot_bytes + 16 + 12 * W;
+    };
+    while (c > 1 && lds_need(c, 20) > 160 * 1024) --c;
     // Rescale period 16, or 8 without transition rows: there the last rows of a sweep run through
     // far-off-path cells with nothing slower beside them (the constant-density rows), the wave's
     // largest value collapses ~70 bits per step, and a period of 16 steps overruns the scale-move cap
@@ -1173,19 +1267,27 @@ int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadM
     while ((1 << rsh) <= c + mel) rsh++;
     // history ring: ages 1 .. c+mel are read; the oldest slot is read and then overwritten in the
     // same step (LDS operations of one wave execute in program order)
-    const int H = c + mel > 0 ? c + mel : 1;
+    // (a team's ring has one slot more: across waves "read the oldest slot, then overwrite it" is a race)
+    const int H = (c + mel > 0 ? c + mel : 1) + (W > 1 ? 1 : 0);
     int SR = 256;
-    while (SR < 64 * c + CH) SR <<= 1;
-    const size_t lds = (size_t)ETN * 8 + (size_t)SR * 8 + (size_t)H * 64 * 20 + 20 + 16;  // + the zero entry
-    const size_t lds_rev = (size_t)ETN * 8 + (size_t)SR * 8 + (size_t)H * 64 * 8 + 8 + 16;  // reverse-only launch
+    while (SR < 64 * c + CH) SR <<= 1;  // per wave
+    // exp table + the waves' signal rings + history ring (+ its zero entry) + work item / team exchange words
+    const size_t lds = lds_need(c, 20);
+    const size_t lds_rev = lds_need(c, 8);  // reverse-only launch
     if (lds > 160 * 1024) return NVK_ERR_UNSUPPORTED;
-    int per_cu = (int)((160 * 1024) / lds);
-    if (per_cu > 4 * NVK_LB) per_cu = 4 * NVK_LB;
+    int per_cu = (int)((160 * 1024) / lds);          // workgroups (waves, or teams of W waves) per CU
+    if (per_cu > 4 * NVK_LB / W) per_cu = 4 * NVK_LB / W;
     if (per_cu < 1) per_cu = 1;
     int per_cu_rev = (int)((160 * 1024) / lds_rev);
-    if (per_cu_rev > 4 * NVK_LB_REV) per_cu_rev = 4 * NVK_LB_REV;
+    if (per_cu_rev > 4 * (W > 1 ? NVK_LB_REV_TEAM : NVK_LB_REV) / W) per_cu_rev = 4 * (W > 1 ? NVK_LB_REV_TEAM : NVK_LB_REV) / W;
     if (per_cu_rev < 1) per_cu_rev = 1;
+#if NVK_TWO_PHASE
+    int32_t mxpad = 1;  // the longest read of the batch under the offsets the kernels use (ReadMeta::pad)
+    for (int32_t v : steps_sorted) mxpad = v > mxpad ? v : mxpad;
+    const int64_t bp_stride = (int64_t)((mxpad + 31) / 32 + 1) * TLk;
+#else
     const int64_t bp_stride = (int64_t)((max_steps + 31) / 32 + 1) * 64;
+#endif
     const int64_t cap = nvk_spill_cap(ctx, WS_SPILL);
 
     Align3Args g;
@@ -1201,7 +1303,7 @@ int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadM
     g.SR = SR;
     g.transitions = transitions;
     g.c_lo = cls[k].lo;
-    g.c_cap = cls[k].hi;
+    g.c_cap = c;
     g.flag_above = (k == ncls - 1) ? 1 : 0;
     g.rsh = rsh;
     g.rstate = (int2 *)ctx->ws[WS_RSTATE];
@@ -1210,7 +1312,8 @@ int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadM
     g.ties = (int32_t *)ctx->ws[WS_TIES];
     g.out_events = out_events;
     g.out_status = out_status;
-    void (**kern)(Align3Args) = (rsh == 4) ? k16 : kv;
+    void (**kern)(Align3Args) = (W > 1) ? kt : ((rsh == 4) ? k16 : kv);
+    if (W > 1 && !kern[1]) return NVK_ERR_UNSUPPORTED;  // (one-launch development build)
     for (int ph = 0; ph < 3; ph++)
       if (kern[ph] && (ph == 1 ? lds_rev : lds) > 64 * 1024)
         NVK_HIP(hipFuncSetAttribute((const void *)kern[ph], hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1222,14 +1325,14 @@ int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadM
       int64_t hi = lo, mx = 1;
       while (hi < a.n_reads) {
         const int64_t m2 = steps_sorted[(size_t)hi] > mx ? steps_sorted[(size_t)hi] : mx;
-        if (hi > lo && (m2 + 2 * PF) * 512 * (hi - lo + 1) > cap) break;
+        if (hi > lo && (m2 + 2 * PF) * 512 * W * (hi - lo + 1) > cap) break;
         mx = m2;
         ++hi;
       }
       const int64_t n_chunk = hi - lo;
       const int64_t spill_stride = (mx + 2 * PF) * 64;
       const int64_t L_stride = (mx >> rsh) + 4;
-      rc = nvk_ws_reserve(ctx, WS_SPILL, (size_t)n_chunk * spill_stride * 8);
+      rc = nvk_ws_reserve(ctx, WS_SPILL, (size_t)n_chunk * W * spill_stride * 8);
       if (rc) return rc;
       rc = nvk_ws_reserve(ctx, WS_STAGE, (size_t)n_chunk * L_stride * 4);
       if (rc) return rc;
@@ -1247,9 +1350,9 @@ int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadM
       g.n_reads = (int)n_chunk;
       g.read_lo = (int)lo;
       NVK_HIP(hipMemsetAsync(counter, 0, sizeof(int), ctx->stream));
-      hipLaunchKernelGGL(kern[1], dim3((unsigned)slots_r), dim3(64), lds_rev, ctx->stream, g);
+      hipLaunchKernelGGL(kern[1], dim3((unsigned)slots_r), dim3(TLk), lds_rev, ctx->stream, g);
       NVK_HIP(hipMemsetAsync(counter, 0, sizeof(int), ctx->stream));
-      hipLaunchKernelGGL(kern[2], dim3((unsigned)slots_f), dim3(64), lds, ctx->stream, g);
+      hipLaunchKernelGGL(kern[2], dim3((unsigned)slots_f), dim3(TLk), lds, ctx->stream, g);
       NVK_HIP(hipGetLastError());
       lo = hi;
     }

@@ -185,6 +185,8 @@ __global__ __launch_bounds__(PLAN_T) void plan_kernel(DeviceModel dm, BatchArgs 
   m.status = NVK_READ_OK;
   m.pad = 0;
   m.cells = 0;
+  m.cw = 0;
+  m.rsv = 0;
   int T;
   if (mode == PLAN_ALIGN_TRANS) {
     T = 2 * R;
@@ -279,6 +281,27 @@ __global__ __launch_bounds__(PLAN_T) void plan_kernel(DeviceModel dm, BatchArgs 
   __syncthreads();
   const int c = sh_c;
   cells = (long long)sh_cells;
+  // A band this wide for its row spacing (skew above the main launch's cap) is served by a TEAM of waves
+  // (kernels_align3.hip): 64 * ALIGN3_TEAM_W lanes, one row each, so a lane's next row lies that many rows
+  // on and the skew it needs is that of the row pair (r - 64 W, r) — on long reads with wide bands the band
+  // moves on by more samples in 256 rows than it is wide, and the skew falls from ~28 to ~3.
+  const bool team = (c > c_cap);
+  int cw = 0;
+  if (team) {
+    constexpr int TL = 64 * ALIGN3_TEAM_W;
+    __shared__ int sh_cw;
+    if (tid == 0) sh_cw = max(mel - 1, 1);
+    __syncthreads();
+    int need = 1;
+    for (int r = TL + tid; r < T; r += PLAN_T) {
+      int d = rp[r - TL].hi - rp[r].lo;  // need TL * cw > d
+      if (d >= 0) need = max(need, d / TL + 1);
+    }
+    need = wave_max(need);
+    if (lane == 0) atomicMax(&sh_cw, need);
+    __syncthreads();
+    cw = sh_cw;
+  }
 
   // --- per-row time offsets (variable skew, used by kernels_align3.hip) ---------------------------
   // The uniform mapping t = i + c*r pays the worst pair of rows (r - 64, r) of the read on every row.
@@ -302,7 +325,7 @@ __global__ __launch_bounds__(PLAN_T) void plan_kernel(DeviceModel dm, BatchArgs 
   const bool neg_gaps = (mode == PLAN_ALIGN_TRANS) && mel <= 2;
   if (tid == 0) sh_var = 0;
   __syncthreads();
-  if (T <= VT && T > 64 && (neg_gaps || c > gmin)) {
+  if (!team && T <= VT && T > 64 && (neg_gaps || c > gmin)) {
     for (int r = tid; r < T; r += PLAN_T) {
       int g = 0;
       if (r > 0) {
@@ -382,13 +405,15 @@ __global__ __launch_bounds__(PLAN_T) void plan_kernel(DeviceModel dm, BatchArgs 
   }
   const bool var_ok = (sh_var != 0);
   const int x0 = var_ok ? sh_x[0] : 0;
-  for (int r = tid; r < T; r += PLAN_T) rp[r].off = var_ok ? sh_x[r] - x0 + sh_S[r] : c * r;
-  const int off_top = var_ok ? sh_x[T - 1] - x0 + sh_S[T - 1] : c * (T - 1);
+  const int cu = team ? cw : c;  // uniform offsets
+  for (int r = tid; r < T; r += PLAN_T) rp[r].off = var_ok ? sh_x[r] - x0 + sh_S[r] : cu * r;
+  const int off_top = var_ok ? sh_x[T - 1] - x0 + sh_S[T - 1] : cu * (T - 1);
 
   if (tid == 0) {
     int t_min = rp[0].lo;
     int t_max = rp[T - 1].hi + c * (T - 1);
     m.c = c;
+    m.cw = cw;
     m.t_min = t_min;
     m.n_steps = t_max - t_min + 1;
     m.pad = rp[T - 1].hi + off_top - t_min + 1;  // steps under the per-row offsets ...
@@ -399,6 +424,7 @@ __global__ __launch_bounds__(PLAN_T) void plan_kernel(DeviceModel dm, BatchArgs 
     if (!badband) {
       atomicMax(&totals->max_steps, m.n_steps);
       atomicMax(&totals->max_c, c);
+      atomicMax(&totals->max_cw, cw);
       if (c > c_cap) atomicAdd(&totals->n_wide, 1);
       atomicMax(&totals->max_T, T);
       atomicAdd(&totals->cells, (unsigned long long)cells);
@@ -450,6 +476,8 @@ __global__ __launch_bounds__(64) void plan_ell_kernel(DeviceModel dm, BatchArgs 
   m.status = NVK_READ_OK;
   m.pad = 0;
   m.cells = 0;
+  m.cw = 0;
+  m.rsv = 0;
 
   int bad = read_is_bad(dm, a, rd, lane, 64);
   bad = __any(bad);

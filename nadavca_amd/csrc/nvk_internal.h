@@ -48,6 +48,9 @@ struct ReadMeta {
   int32_t status;    // NVK_READ_*
   int32_t pad;       // align planner: number of steps under the per-row offsets RowParam::off
   int64_t cells;     // sum of band widths (algorithmic cell count)
+  int32_t cw;        // align planner: 0, or the skew of a read served by a TEAM of ALIGN3_TEAM_W waves
+                     // (kernels_align3.hip: one row per lane of 64 * ALIGN3_TEAM_W lanes; RowParam::off = cw * r)
+  int32_t rsv;
 };
 
 // totals reduced over a batch by the planner (read back once by the host)
@@ -57,6 +60,7 @@ struct PlanTotals {
   int32_t max_c;
   int32_t max_T;
   int32_t max_W;
+  int32_t max_cw;   // largest team skew (ReadMeta::cw)
   unsigned long long cells;
   unsigned long long steps;
 };
@@ -162,6 +166,7 @@ int launch_count_flags(nvk_ctx *ctx, const int32_t *flags, int64_t n, int32_t *o
 int64_t nvk_spill_cap(nvk_ctx *ctx, int which_ws);
 // internal per-read status of the scaled-double kernel: the exact kernel must redo this read
 constexpr int NVK_READ_RETRY_INTERNAL = 2;
+constexpr int ALIGN3_TEAM_W = 4;  // waves per read for wide bands (skew above ALIGN1_C_CAP with one wave)
 constexpr int ALIGN1_C_CAP = 3;  // skew served by the main launch of the one-read-per-wave kernel
 // only_retry != 0: serve only the reads whose out_status is NVK_READ_RETRY_INTERNAL
 int launch_align_retry(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadMeta *metas,
