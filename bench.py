@@ -262,7 +262,8 @@ def main():
         if not is_api:
             cfg.update({'samples_per_read': round(dbatch.total_signal / n_reads, 1),
                         'bases_per_read': round(dbatch.total_ref / n_reads, 1),
-                        'band_cells_per_read': round(stats['band_cells'] / n_reads, 1)})
+                        'band_cells_per_read': round(stats['band_cells'] / n_reads, 1),
+                        'wave_steps_per_read': round(stats['wave_steps'] / n_reads, 1)})
         if wname == 'api_estimate_snps':
             cfg.update({'tweak_signal_normalization': not args.no_tweak, 'fit_workers': args.fit_workers,
                         'chunk_groups': extra.get('chunks')})

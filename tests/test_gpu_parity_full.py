@@ -120,6 +120,35 @@ def test_random_models_mismatches_are_flagged(oracle_port):
     print('random models: %d reads, %d flagged, %d differ (all flagged)' % (n_reads, n_flag, n_diff))
 
 
+def test_wide_band_reads_swept_by_teams_of_waves(oracle_port):
+    """Bands too wide for one wave's rings (skew above the main launch's cap) are swept by teams of four waves
+    (kernels_align3.hip, W > 1): random bandwidths 100-700 on reads of 1-700 bases, min event length 0-4,
+    transitions on/off, narrow reads mixed in (tests/dev/fuzz_team.py runs the same generator for minutes).
+    Every read equals the reference or carries the tie flag; most are equal."""
+    from fuzz_cases import make_team_batch, reads_of
+    from nadavca_amd import dtw, _lib
+    ctx = _lib.default_context()
+    n_reads = n_diff = n_flag = 0
+    for it in range(120):
+        fb = make_team_batch(77, it)
+        mg = dtw.KmerModel(*fb['model'], context=ctx)
+        mo = oracle_port.KmerModel(*fb['model'])
+        reads = reads_of(fb['cases'])
+        got = dtw.refine_alignment_batch(reads, fb['bw'], fb['mel'], mg, fb['tr'])
+        flags = ctx.last_tie_flags(len(reads))
+        for j, c in enumerate(fb['cases']):
+            exp = oracle_port.refine_alignment(c['signal'], c['reference'], c['context_before'], c['context_after'],
+                                               c['approximate_alignment'], fb['bw'], fb['mel'], mo, fb['tr'])
+            same = _same(got[j], exp)
+            n_reads += 1
+            n_diff += (not same)
+            n_flag += int(flags[j] != 0)
+            assert same or flags[j] != 0, ('unflagged read differs', it, j)
+        mg.close()
+    assert n_diff * 10 < n_reads
+    print('wide bands (teams): %d reads, %d flagged, %d differ (all flagged)' % (n_reads, n_flag, n_diff))
+
+
 @pytest.fixture(scope='module')
 def cfg5_cases():
     from nadavca_amd import synthetic
