@@ -6,7 +6,7 @@
  * and bench.py's cpu_baseline leg may load this; the product library
  * (nadavca_amd/csrc) never links or calls it.
  *
- * Parity status: PINNED.  oracle/check_oracle.py compares every entry point
+ * Parity status: PINNED.  tests/test_oracle_golden.py compares every entry point
  * against oracle/_ref/libnadavca_ref.so (the reference's own sources compiled in
  * place) and against the committed fixtures in tests/golden/ that were produced
  * by that build (oracle/make_golden.py); alignments are equal and
