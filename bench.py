@@ -86,11 +86,16 @@ def cpu_baseline(batch, model, bandwidth, mel, workload, budget_reads_per_core=2
             'per_core': n / dt / cores}
 
 
+PROFILE_FIGURES_OFF = False  # set for runs the committed counter profiles do not describe (--k: other kernels)
+
+
 def profile_figure(workload, key):
     """A figure that cannot be read from inside this process (HBM bytes, instruction counts: PMC counters)
     from the newest committed rocprofv3 summary profiles/*_counters.json for this workload, per read, with
     its provenance: -> (value per read or None, source file or None)."""
     import glob
+    if PROFILE_FIGURES_OFF:
+        return None, None
     for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_counters.json')), reverse=True):
         try:
             t = json.load(open(path))
@@ -117,6 +122,8 @@ def main():
     ap.add_argument('--k', type=int, default=0, help='use a synthetic k-mer table of this size (e.g. 10: the size of the '
                     "reference's coded default table, 4^10 rows) instead of the packaged 6-mer table")
     args = ap.parse_args()
+    global PROFILE_FIGURES_OFF
+    PROFILE_FIGURES_OFF = bool(args.k)
 
     import torch
     rank = int(os.environ.get('RANK', '0'))
