@@ -86,6 +86,18 @@ def cpu_baseline(batch, model, bandwidth, mel, workload, budget_reads_per_core=2
             'per_core': n / dt / cores}
 
 
+def kernel_source_hash(root):
+    """sha1 over the HIP sources and headers of the library (the build the counters describe)."""
+    import glob, hashlib
+    h = hashlib.sha1()
+    for path in sorted(glob.glob(os.path.join(root, 'nadavca_amd', 'csrc', '*.hip')) +
+                       glob.glob(os.path.join(root, 'nadavca_amd', 'csrc', '*.h')) +
+                       glob.glob(os.path.join(root, 'include', '*.h'))):
+        h.update(os.path.basename(path).encode())
+        h.update(open(path, 'rb').read())
+    return h.hexdigest()
+
+
 PROFILE_FIGURES_OFF = False  # set for runs the committed counter profiles do not describe (--k: other kernels)
 
 
@@ -102,6 +114,9 @@ def profile_figure(workload, key):
         except Exception:
             continue
         if t.get('workload') == workload and key in t:
+            # figures of another build of the kernels are not quoted (no stale canned numbers)
+            if t.get('kernel_source_sha1') not in (None, kernel_source_hash(ROOT)):
+                return None, os.path.relpath(path, ROOT) + ' (stale: other kernel sources, not quoted)'
             return t[key], os.path.relpath(path, ROOT)
     return None, None
 

@@ -73,8 +73,22 @@ def main():
          'valu_insts_per_read': valu / n if valu else None,
          'salu_insts_per_read': per('SQ_INSTS_SALU') / n if per('SQ_INSTS_SALU') else None,
          'valu_busy_frac': (act * 4.0) / (gui_all / 8.0 * 1024.0) if act and gui_all else None}
+    j['kernel_source_sha1'] = kernel_source_hash(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     json.dump(j, open(os.path.join(out, tag + '_counters.json'), 'w'), indent=1)
     print('# wrote %s_counters.json: %s' % (tag, {k: j[k] for k in ('hbm_bytes_per_read', 'valu_insts_per_read', 'valu_busy_frac')}))
+
+
+
+def kernel_source_hash(root):
+    """sha1 over the HIP sources and headers of the library (the build the counters describe)."""
+    import glob, hashlib
+    h = hashlib.sha1()
+    for path in sorted(glob.glob(os.path.join(root, 'nadavca_amd', 'csrc', '*.hip')) +
+                       glob.glob(os.path.join(root, 'nadavca_amd', 'csrc', '*.h')) +
+                       glob.glob(os.path.join(root, 'include', '*.h'))):
+        h.update(os.path.basename(path).encode())
+        h.update(open(path, 'rb').read())
+    return h.hexdigest()
 
 
 if __name__ == '__main__':
