@@ -80,11 +80,13 @@ using dens::density_end;
 using dens::DensHalf;
 using dens::ETN;
 
-constexpr int CH = 64;      // signal refill chunk (samples)
+constexpr int CH = 64;      // signal refill chunk (samples): one per lane
+static_assert(CH == 64, "a refill is one sample per lane");
 #ifndef NVK_PF
 #define NVK_PF 8
 #endif
 constexpr int PF = NVK_PF;       // forward sweep: spill prefetch depth (steps) = steps per loop trip
+static_assert(32 % PF == 0 && PF % 2 == 0, "the step count is a multiple of 32 (kernels_plan.hip)");
 // rescale period: 2^rsh steps (launch parameter, >= 16); must exceed c + mel so that at most one
 // rescale lies inside the window a neighbour value travels through
 constexpr int GBIG = 1 << 24;  // scale of an empty running maximum (see the path step)
@@ -344,7 +346,7 @@ struct Scale {
 #define NVK_LB 4
 #endif
 #ifndef NVK_LB_REV
-#define NVK_LB_REV 7
+#define NVK_LB_REV 6
 #endif
 #define NVK_LB_REV_TEAM 6  // (the team's reverse sweep needs 76 registers: 80 without spills)
 //
@@ -481,7 +483,8 @@ __global__ __launch_bounds__(64 * W, PHASE == 1 ? (W > 1 ? NVK_LB_REV_TEAM : NVK
       double o_hold = 0.0;  // the value of the even step of a trip, stored together with the odd step's
       int kmax = -0x40000000;
       int r_old = (W == 1) ? top : max(wave_max_i(r), -1);  // the oldest open row of this wave
-      int i_old = __builtin_amdgcn_readlane(i, r_old & 63);  // sample index of the oldest open row (scalar)
+      // sample index of the oldest open row (scalar); no row at all: a value no refill test reaches
+      int i_old = (r_old >= 0) ? __builtin_amdgcn_readlane(i, r_old & 63) : 0x40000000;
       int filled_lo = (i_old / CH + 1) * CH;
       while (i_old - 3 < filled_lo) {
         filled_lo -= CH;
@@ -489,6 +492,13 @@ __global__ __launch_bounds__(64 * W, PHASE == 1 ? (W > 1 ? NVK_LB_REV_TEAM : NVK
           int idx = filled_lo + q;
           ring[idx & RM] = (idx >= 0 && idx < N) ? sig[idx] : 0.0;
         }
+      }
+      // the chunk below the filled ones, loaded one refill ahead: a refill then writes a value that arrived long
+      // ago instead of waiting for a fresh load (and, with it, for every spill access in flight)
+      double nxt;
+      {
+        const int idx = filled_lo - CH + lane;
+        nxt = (idx >= 0 && idx < N) ? sig[idx] : 0.0;
       }
       __syncthreads();
       Scale sc{0, 0, 0};
@@ -514,8 +524,7 @@ __global__ __launch_bounds__(64 * W, PHASE == 1 ? (W > 1 ? NVK_LB_REV_TEAM : NVK
       for (int ub = 0; ub < n_steps; ub += 2) {
 #pragma unroll
       for (int uq = 0; uq < 2; uq++) {
-        const int u = ub + uq;
-        if (u >= n_steps) break;
+        const int u = ub + uq;  // (n_steps is a multiple of 32, kernels_plan.hip: no end test inside a trip)
         const int t = t_max - u;
         // this step's shift was decided at the end of the previous one
         const int age = u & (RS - 1);  // steps since the last rescale step (the scale only moves there)
@@ -572,20 +581,22 @@ __global__ __launch_bounds__(64 * W, PHASE == 1 ? (W > 1 ? NVK_LB_REV_TEAM : NVK
           }
           while (r_old >= 0 && __builtin_amdgcn_readlane(r, r_old & 63) != r_old)
             r_old -= (W > 1 && (r_old & 63) == 0) ? 1 + 64 * (W - 1) : 1;  // (the wave's rows only)
-          i_old = __builtin_amdgcn_readlane(i, r_old & 63);
+          // (no open row left: a sample index no refill test ever reaches)
+          i_old = (r_old >= 0) ? __builtin_amdgcn_readlane(i, r_old & 63) : 0x40000000;
           init_live &= (__builtin_amdgcn_readlane(r, top & 63) == top) ? 1 : 0;
           row0_live = (__builtin_amdgcn_readfirstlane(r) == 0) ? 1 : 0;
         }
-        if (r_old >= 0) {
+        {
           // (a younger row may be one sample beyond the oldest one; PAIR: and its partner evaluates one
           // sample further ahead)
           const int need_min = i_old - (PAIR ? 3 : 2);
           while (need_min < filled_lo) {
             filled_lo -= CH;
             RING_SYNC();
-            for (int q = lane; q < CH; q += 64) {
-              int idx = filled_lo + q;
-              ring[idx & RM] = (idx >= 0 && idx < N) ? sig[idx] : 0.0;
+            ring[(filled_lo + lane) & RM] = nxt;
+            {
+              const int idx = filled_lo - CH + lane;
+              nxt = (idx >= 0 && idx < N) ? sig[idx] : 0.0;
             }
             RING_SYNC();
           }
@@ -634,18 +645,19 @@ __global__ __launch_bounds__(64 * W, PHASE == 1 ? (W > 1 ? NVK_LB_REV_TEAM : NVK
         }
         const double ee = PAIR ? fma(e, pm, cq) : e;  // the transition lane's own density is its constant
         double o = fma(ee, prev, t1);  // zero outside the lane's span, see Lane3::pA
-        if (init_live) {
-          asm volatile("");
-          if (is_init) o = ACTIVE_R ? ldexp(1.0, sc.L) : 0.0;
-        }
         // Cells far off the likely path are thousands of bits below the wave's largest value and
         // flush to zero here; that cannot change any value that matters (their contributions are
         // below 2^-53 of it in exact arithmetic too).  Overflow / NaN must never happen.
-        prev = o;
-        if (row0_live) {  // row 0 lives on lane 0; only its kmax is read
+        if (init_live | row0_live) {  // (one scalar test for the two rare cases: the first and the last row)
           asm volatile("");
-          if (o != 0.0) kmax = max(kmax, __builtin_amdgcn_frexp_exp(o) - sc.L);
+          if (init_live) {
+            if (is_init) o = ACTIVE_R ? ldexp(1.0, sc.L) : 0.0;
+          }
+          if (row0_live) {  // row 0 lives on lane 0; only its kmax is read
+            if (o != 0.0) kmax = max(kmax, __builtin_amdgcn_frexp_exp(o) - sc.L);
+          }
         }
+        prev = o;
 #if NVK_ABL == 10
         if (!(uq & 1)) *reinterpret_cast<double *>(histb + (su * (8 * TL) + gl8)) = o;
 #elif NVK_ABL != 7
@@ -776,7 +788,7 @@ __global__ __launch_bounds__(64 * W, PHASE == 1 ? (W > 1 ? NVK_LB_REV_TEAM : NVK
       uint32_t bits = 0;
       int r_old = min(64 * wv, T);  // the oldest open row of this wave
       // sample index of the oldest open row (scalar): t_min for row 0 (offs[0] = 0)
-      int i_old = (r_old < T) ? __builtin_amdgcn_readfirstlane(i) : t_min;
+      int i_old = (r_old < T) ? __builtin_amdgcn_readfirstlane(i) : -0x40000000;
       int filled_hi = ((i_old - MEL - 1) > 0 ? (i_old - MEL - 1) / CH : 0) * CH;
       while (i_old + 2 >= filled_hi) {
         for (int w = lane; w < CH; w += 64) {
@@ -784,6 +796,11 @@ __global__ __launch_bounds__(64 * W, PHASE == 1 ? (W > 1 ? NVK_LB_REV_TEAM : NVK
           ring[idx & RM] = (idx >= 0 && idx < N) ? sig[idx] : 0.0;
         }
         filled_hi += CH;
+      }
+      double nxt;  // the chunk above the filled ones, loaded one refill ahead (see the reverse sweep)
+      {
+        const int idx = filled_hi + lane;
+        nxt = (idx >= 0 && idx < N) ? sig[idx] : 0.0;
       }
       __syncthreads();
       Scale sc{0, 0, 0};
@@ -819,7 +836,7 @@ __global__ __launch_bounds__(64 * W, PHASE == 1 ? (W > 1 ? NVK_LB_REV_TEAM : NVK
 #pragma unroll
         for (int q = 0; q < PF; q++) {
           const int u = ub + q;
-          if (u < n_steps) {
+          {  // (n_steps is a multiple of 32 = 4 trips: no end test inside a trip)
             const int age = u & (RS - 1);
             if (age == 0 && u > 0) {
               sc.L += sc.d_next;
@@ -873,19 +890,21 @@ __global__ __launch_bounds__(64 * W, PHASE == 1 ? (W > 1 ? NVK_LB_REV_TEAM : NVK
               }
               while (r_old < T && __builtin_amdgcn_readlane(r, r_old & 63) != r_old)
                 r_old += (W > 1 && (r_old & 63) == 63) ? 1 + 64 * (W - 1) : 1;  // (the wave's rows only)
-              i_old = __builtin_amdgcn_readlane(i, r_old & 63);
+              // (no open row left: a sample index no refill test ever reaches)
+              i_old = (r_old < T) ? __builtin_amdgcn_readlane(i, r_old & 63) : -0x40000000;
               init_live &= (__builtin_amdgcn_readfirstlane(r) == 0) ? 1 : 0;
               top_live = (__builtin_amdgcn_readlane(r, top & 63) == top) ? 1 : 0;
             }
-            if (r_old < T) {
+            {
               const int need_max = i_old + (PAIR ? 2 : 1);  // (PAIR: the partner evaluates one sample further ahead)
               while (need_max >= filled_hi) {
                 RING_SYNC();
-                for (int w = lane; w < CH; w += 64) {
-                  int idx = filled_hi + w;
-                  ring[idx & RM] = (idx >= 0 && idx < N) ? sig[idx] : 0.0;
-                }
+                ring[(filled_hi + lane) & RM] = nxt;
                 filled_hi += CH;
+                {
+                  const int idx = filled_hi + lane;
+                  nxt = (idx >= 0 && idx < N) ? sig[idx] : 0.0;
+                }
                 RING_SYNC();
               }
             }
@@ -932,22 +951,18 @@ __global__ __launch_bounds__(64 * W, PHASE == 1 ? (W > 1 ? NVK_LB_REV_TEAM : NVK
             }
             const double ee = PAIR ? fma(e, pm, cq) : e;
             double o = fma(ee, prev, t1);
-            if (init_live) {
-              asm volatile("");
-              if (is_init) o = IN_BAND ? ldexp(1.0, sc.L) : 0.0;
-            }
-            prev = o;
+            // (row 0's cells are set, not computed: with the other rare case, the last row's arg-max, below)
             // ---- posterior of the cell, on the scale 2^-K:  post = prefix * suffix
             const double suf = (q & 1) ? cur_v[q >> 1].y : cur_v[q >> 1].x;
             const int ur = n_steps - 1 - u;  // the reverse sweep's step for this anti-diagonal
-            if ((ur & (RS - 1)) == RS - 1 || u == 0) Lrev = sL[ur >> RSH];
+            // (a compiled-in period divides n_steps: the reverse sweep's rescale steps are this sweep's age-0 steps)
+            if (RSHC ? (age == 0) : ((ur & (RS - 1)) == RS - 1 || u == 0)) Lrev = sL[ur >> RSH];
             const int kap = -(sc.L + K) - Lrev;  // scalar
             // No band test here: a cell of the lane's warm-up (lo <= i < bs) has suf == 0, because the
             // reverse sweep's lane was idle at this (step, lane) — it leaves row r at bs and the planner
             // keeps its next row (r - 64) from reaching back into [lo, be] of row r — and beyond `be`
             // o is 0.  (A violation would show up in the row-mass check.)
-            const double post = ldexp(o * suf, kap);
-            rsum += post;
+            double post = ldexp(o * suf, kap);
             // ---- path step (node.cpp:52-91): running maximum of the previous row, strict '>' at the
             // resolution of the reference's log-doubles (xm::gt_tol): margin = best * |exponent| * 2^-52
             // Scores are (double, integer scale): stored = true * 2^scale.  The running maximum is kept
@@ -977,12 +992,16 @@ __global__ __launch_bounds__(64 * W, PHASE == 1 ? (W > 1 ? NVK_LB_REV_TEAM : NVK
             bits = (bits << 1) | (upd ? 1u : 0u);  // step u ends up at bit 31 - (u & 31)
             double dpv = bestn * post;  // post is already 0 outside the band
             int Gd = G;
-            if (init_live) {
+            if (init_live | top_live) {  // (one scalar test for the two rare cases: the first and the last row)
               asm volatile("");
-              if (is_init) { dpv = post; Gd = 0; }
-            }
-            if (top_live) {
-              asm volatile("");
+              if (init_live) {
+                if (is_init) {
+                  o = IN_BAND ? ldexp(1.0, sc.L) : 0.0;
+                  post = ldexp(o * suf, kap);
+                  dpv = post; Gd = 0;
+                }
+              }
+              if (top_live) {
               const double da = ldexp(dpv, (fbest == 0.0) ? 0 : fG - Gd);
               amb |= __builtin_amdgcn_ballot_w64(r == top && IN_BAND && fabs(da - fbest) < da * TIE_FLAG_REL);
               if (r == top && IN_BAND && (da - fbest > fthr)) {
@@ -991,12 +1010,15 @@ __global__ __launch_bounds__(64 * W, PHASE == 1 ? (W > 1 ? NVK_LB_REV_TEAM : NVK
                 fidx = i;
                 fthr = dpv * ((double)abs(__builtin_amdgcn_frexp_exp(dpv) - Gd) * 0x1.0p-52);
               }
+              }
             }
+            prev = o;
+            rsum += post;
 #if NVK_ABL != 7
             *reinterpret_cast<double2 *>(histb + (su * (16 * TL) + gl16)) = make_double2(o, dpv);
             *reinterpret_cast<int *>(ghistb + (su * (4 * TL) + (gl16 >> 2))) = Gd;
 #endif
-            if ((u & 31) == 31 || u == n_steps - 1) {
+            if ((u & 31) == 31) {
               int w = u >> 5;
               asm volatile("" : "+s"(w));  // keeps the address arithmetic inside the branch
               bp[(size_t)w * TL + gl] = bits << (31 - (u & 31));

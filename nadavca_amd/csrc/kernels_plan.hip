@@ -417,7 +417,9 @@ __global__ __launch_bounds__(PLAN_T) void plan_kernel(DeviceModel dm, BatchArgs 
     m.t_min = t_min;
     m.n_steps = t_max - t_min + 1;
     m.pad = rp[T - 1].hi + off_top - t_min + 1;  // steps under the per-row offsets ...
-    m.pad += m.pad & 1;  // ... made even: kernels_align3 spills two steps per access
+    // ... rounded up to a multiple of 32: kernels_align3 spills two steps per access, unrolls 8, rescales every
+    // 16 and flushes its bit words every 32 steps, and with a whole number of each its loops need no end tests
+    m.pad = (m.pad + 31) & ~31;
     m.cells = cells;
     if (badband) m.status = NVK_READ_BAD_BAND;
     metas[rd] = m;
