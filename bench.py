@@ -124,8 +124,8 @@ def profile_figure(workload, key):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--workload', default='cfg2_align',
                     choices=['cfg2_align', 'cfg3_snps', 'cfg4_consensus', 'cfg5_long', 'api_align_signal',
                              'api_estimate_snps'])
