@@ -90,6 +90,13 @@ constexpr int PF = NVK_PF;       // forward sweep: spill prefetch depth (steps) 
 #define NVK_RU 16
 #endif
 constexpr int RU = NVK_RU;       // reverse sweep: steps per loop trip
+#ifndef NVK_FT
+#define NVK_FT 16
+#endif
+// forward sweep: steps per loop trip, a multiple of the prefetch depth (16: with the compiled-in rescale period
+// of 16 the step's position in the period is static; measured 8 -> 16: -2.3 %, 32: slower again — 128 registers)
+constexpr int FT = NVK_FT;
+static_assert(FT % PF == 0 && 32 % FT == 0, "forward trip");
 static_assert(32 % PF == 0 && PF % 2 == 0 && 32 % RU == 0 && RU % 2 == 0, "the step count is a multiple of 32 (kernels_plan.hip)");
 // rescale period: 2^rsh steps (launch parameter, >= 16); must exceed c + mel so that at most one
 // rescale lies inside the window a neighbour value travels through
@@ -837,9 +844,9 @@ __global__ __launch_bounds__(64 * W, PHASE == 1 ? (W > 1 ? NVK_LB_REV_TEAM : NVK
       // (16 steps per trip would make `age` a compile-time constant and most rare-path tests static;
       // measured: 18.7 instead of 17.6 ms — the loop no longer fits the instruction cache.  4 steps per
       // trip: 17.8 ms.)
-      for (int ub = 0; ub < n_steps; ub += PF) {
+      for (int ub = 0; ub < n_steps; ub += FT) {
 #pragma unroll
-        for (int q = 0; q < PF; q++) {
+        for (int q = 0; q < FT; q++) {
           const int u = ub + q;
           {  // (n_steps is a multiple of 32 = 4 trips: no end test inside a trip)
             const int age = u & (RS - 1);
@@ -958,7 +965,7 @@ __global__ __launch_bounds__(64 * W, PHASE == 1 ? (W > 1 ? NVK_LB_REV_TEAM : NVK
             double o = fma(ee, prev, t1);
             // (row 0's cells are set, not computed: with the other rare case, the last row's arg-max, below)
             // ---- posterior of the cell, on the scale 2^-K:  post = prefix * suffix
-            const double suf = (q & 1) ? cur_v[q >> 1].y : cur_v[q >> 1].x;
+            const double suf = (q & 1) ? cur_v[(q % PF) >> 1].y : cur_v[(q % PF) >> 1].x;
             const int ur = n_steps - 1 - u;  // the reverse sweep's step for this anti-diagonal
             // (a compiled-in period divides n_steps: the reverse sweep's rescale steps are this sweep's age-0 steps)
             if (RSHC ? (age == 0) : ((ur & (RS - 1)) == RS - 1 || u == 0)) Lrev = sL[ur >> RSH];
@@ -1031,7 +1038,7 @@ __global__ __launch_bounds__(64 * W, PHASE == 1 ? (W > 1 ? NVK_LB_REV_TEAM : NVK
             }
             // refill the prefetch slot just consumed
 #if NVK_ABL != 4 && NVK_ABL != 9
-            if (q & 1) cur_v[q >> 1] = spill_load2(spill_rs, lane16, (u + PF) >> 1);
+            if (q & 1) cur_v[(q % PF) >> 1] = spill_load2(spill_rs, lane16, (u + PF) >> 1);
 #endif
             // ---- rescale decision for the next step, then the next step's density
             if (W > 1 && age == RS - 2) {  // see the reverse sweep
