@@ -551,7 +551,7 @@ __global__ __launch_bounds__(64 * W, PHASE == 1 ? (W > 1 ? NVK_LB_REV_TEAM : NVK
         shift_now = (age == 0 && u > 0) ? sc.d_last : 0;
         bool fin = (i < bs);
         if (__any(fin)) {
-          bool redo = false;  // this lane must re-evaluate the density its `e` stands for
+          bool redo = false;  // this lane has taken a new row
           for (unsigned long long fm = __builtin_amdgcn_ballot_w64(fin); fm != 0; fm &= fm - 1) {
             const int fl = __builtin_ctzll(fm);
             const int rn = __builtin_amdgcn_readlane(r, fl) - TL;  // (uniform) the row that lane takes
@@ -575,21 +575,20 @@ __global__ __launch_bounds__(64 * W, PHASE == 1 ? (W > 1 ? NVK_LB_REV_TEAM : NVK
           }
           if (PAIR) {
             // when an EMITTING lane has switched: every transition lane takes its partner's (possibly
-            // new) row constants and sample index; on an even step its `e` is the partner's density of
-            // the NEXT step, evaluated one step ago with the constants of then: evaluate it again (the
-            // same value unless the partner switched).  (A transition lane's own switch changes nothing
-            // about the densities.)
+            // new) row constants and sample index.  The densities in flight — the emitting lane's `e` of
+            // this step and, on an even step, the one its partner holds for the next step — were evaluated
+            // with the OLD row's constants and are NOT evaluated again: the planner keeps a lane outside
+            // its new row's span for two steps after a switch (one without transition rows), so they are
+            // multiplied into zeros (kernels_plan.hip, `idle`; re-evaluating them here was a dependent
+            // LDS -> table -> polynomial chain inside every switch of an emitting lane).  (A transition
+            // lane's own switch changes nothing about the densities.)
             if (__any(redo && em)) {
               const double pmn = pair_swap(mean), pac = pair_swap(ac2), pmc = pair_swap(mc2);
               const int ip = pair_swap(i);
               if (!em) { mean = pmn; ac2 = pac; mc2 = pmc; }
               const int odd = u & 1;
-              redo = em ? redo : !odd;
-              if (redo) e = density(ring[(em ? i : ip - 1) & RM], mean, ac2, mc2, em ? shift_now : 0, etab);
               ia = (em ? i - 1 : ip - 2) - (odd ? 0 : 1);
             }
-          } else if (redo) {
-            e = density(ring[i & RM], mean, ac2, mc2, shift_now, etab);
           }
           while (r_old >= 0 && __builtin_amdgcn_readlane(r, r_old & 63) != r_old)
             r_old -= (W > 1 && (r_old & 63) == 0) ? 1 + 64 * (W - 1) : 1;  // (the wave's rows only)
@@ -893,12 +892,8 @@ __global__ __launch_bounds__(64 * W, PHASE == 1 ? (W > 1 ? NVK_LB_REV_TEAM : NVK
                   const int ip = pair_swap(i);
                   if (!em) { mean = pmn; ac2 = pac; mc2 = pmc; }
                   const int odd = u & 1;
-                  redo = em ? redo : !odd;
-                  if (redo) e = density(ring[(em ? i - 1 : ip) & RM], mean, ac2, mc2, em ? shift_now : 0, etab);
                   ia = (em ? i : ip + 1) + (odd ? 0 : 1);
                 }
-              } else if (redo) {
-                e = density(ring[(i - 1) & RM], mean, ac2, mc2, shift_now, etab);
               }
               while (r_old < T && __builtin_amdgcn_readlane(r, r_old & 63) != r_old)
                 r_old += (W > 1 && (r_old & 63) == 63) ? 1 + 64 * (W - 1) : 1;  // (the wave's rows only)

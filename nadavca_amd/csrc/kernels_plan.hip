@@ -271,8 +271,13 @@ __global__ __launch_bounds__(PLAN_T) void plan_kernel(DeviceModel dm, BatchArgs 
     rp[r].hi = hi;
   }
   __syncthreads();
+  // A lane starts its next row `idle` steps after it has left the previous one: the density of its first step
+  // on the new row (and, with transition rows, the one its pair partner holds for the step after) was
+  // evaluated with the old row's constants, and kernels_align3 lets those stale values pass through steps
+  // on which the lane is outside its span instead of re-evaluating them at every row switch.
+  const int idle = (mode == PLAN_ALIGN_TRANS) ? 2 : 1;
   for (int r = 64 + tid; r < T; r += PLAN_T) {
-    int d = rp[r - 64].hi - rp[r].lo;  // need 64*c > d
+    int d = rp[r - 64].hi - rp[r].lo + idle;  // need 64*c > d
     if (d >= 0) cneed = max(cneed, d / 64 + 1);
   }
   cneed = max(cneed, max(mel - 1, 1));
@@ -294,7 +299,7 @@ __global__ __launch_bounds__(PLAN_T) void plan_kernel(DeviceModel dm, BatchArgs 
     __syncthreads();
     int need = 1;
     for (int r = TL + tid; r < T; r += PLAN_T) {
-      int d = rp[r - TL].hi - rp[r].lo;  // need TL * cw > d
+      int d = rp[r - TL].hi - rp[r].lo + idle;  // need TL * cw > d
       if (d >= 0) need = max(need, d / TL + 1);
     }
     need = wave_max(need);
@@ -307,7 +312,8 @@ __global__ __launch_bounds__(PLAN_T) void plan_kernel(DeviceModel dm, BatchArgs 
   // The uniform mapping t = i + c*r pays the worst pair of rows (r - 64, r) of the read on every row.
   // Here cell (r, i) is computed at step t = i + off[r] with the LEAST offsets that satisfy
   //   g[r] <= off[r] - off[r-1] <= c            (neighbour values wait at most c + mel steps in LDS)
-  //   off[r] - off[r-64] >= hi[r-64] - lo[r] + 1  (a lane is free before its next row starts)
+  //   off[r] - off[r-64] >= hi[r-64] - lo[r] + 1 + idle  (a lane is free, and idle for `idle` steps, before its
+  //                                                      next row starts)
   // (off[r] = c*r is one solution, so the least one exists and needs no more steps).  The lower bound
   // g[r] is what keeps the neighbour's value at least one step old, age = gap + mel >= 1: 1 for a row
   // fed without emission (mel 0), 1 - mel for a row fed by an emitting step — with transition rows the
@@ -353,7 +359,7 @@ __global__ __launch_bounds__(PLAN_T) void plan_kernel(DeviceModel dm, BatchArgs 
     }
     __syncthreads();
     for (int r = tid; r < T; r += PLAN_T)
-      sh_k[r] = (r >= 64) ? rp[r - 64].hi - rp[r].lo + 1 - (sh_S[r] - sh_S[r - 64]) : 0;
+      sh_k[r] = (r >= 64) ? rp[r - 64].hi - rp[r].lo + 1 + idle - (sh_S[r] - sh_S[r - 64]) : 0;
     __syncthreads();
     if (tid < 64) {
       const int NEG = -0x20000000;
