@@ -587,8 +587,15 @@ __global__ __launch_bounds__(64 * W, PHASE == 1 ? (W > 1 ? NVK_LB_REV_TEAM : NVK
               const int ip = pair_swap(i);
               if (!em) { mean = pmn; ac2 = pac; mc2 = pmc; }
               const int odd = u & 1;
+              if (W > 1) {  // (teams: re-evaluated as before — measured 4 % faster there: a lockstep step is as
+                            // long as its longest chain, and this block's code shapes the compiler's schedule)
+                redo = em ? redo : !odd;
+                if (redo) e = density(ring[(em ? i : ip - 1) & RM], mean, ac2, mc2, em ? shift_now : 0, etab);
+              }
               ia = (em ? i - 1 : ip - 2) - (odd ? 0 : 1);
             }
+          } else if (W > 1 && redo) {
+            e = density(ring[i & RM], mean, ac2, mc2, shift_now, etab);
           }
           while (r_old >= 0 && __builtin_amdgcn_readlane(r, r_old & 63) != r_old)
             r_old -= (W > 1 && (r_old & 63) == 0) ? 1 + 64 * (W - 1) : 1;  // (the wave's rows only)
@@ -892,8 +899,14 @@ __global__ __launch_bounds__(64 * W, PHASE == 1 ? (W > 1 ? NVK_LB_REV_TEAM : NVK
                   const int ip = pair_swap(i);
                   if (!em) { mean = pmn; ac2 = pac; mc2 = pmc; }
                   const int odd = u & 1;
+                  if (W > 1) {  // (see the reverse sweep)
+                    redo = em ? redo : !odd;
+                    if (redo) e = density(ring[(em ? i - 1 : ip) & RM], mean, ac2, mc2, em ? shift_now : 0, etab);
+                  }
                   ia = (em ? i : ip + 1) + (odd ? 0 : 1);
                 }
+              } else if (W > 1 && redo) {
+                e = density(ring[(i - 1) & RM], mean, ac2, mc2, shift_now, etab);
               }
               while (r_old < T && __builtin_amdgcn_readlane(r, r_old & 63) != r_old)
                 r_old += (W > 1 && (r_old & 63) == 63) ? 1 + 64 * (W - 1) : 1;  // (the wave's rows only)
