@@ -80,14 +80,19 @@ def main():
 
 
 def kernel_source_hash(root):
-    """sha1 over the HIP sources and headers of the library (the build the counters describe)."""
-    import glob, hashlib
+    """sha1 over the HIP sources and headers of the library with comments and white space removed (the code the
+    counters describe; editing a comment does not make a profile stale)."""
+    import glob, hashlib, re
     h = hashlib.sha1()
     for path in sorted(glob.glob(os.path.join(root, 'nadavca_amd', 'csrc', '*.hip')) +
                        glob.glob(os.path.join(root, 'nadavca_amd', 'csrc', '*.h')) +
                        glob.glob(os.path.join(root, 'include', '*.h'))):
+        text = open(path, 'r', encoding='utf-8', errors='replace').read()
+        text = re.sub(r'/\*.*?\*/', ' ', text, flags=re.S)
+        text = re.sub(r'//[^\n]*', ' ', text)
+        text = re.sub(r'\s+', ' ', text)
         h.update(os.path.basename(path).encode())
-        h.update(open(path, 'rb').read())
+        h.update(text.encode())
     return h.hexdigest()
 
 
