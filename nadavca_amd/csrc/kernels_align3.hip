@@ -29,11 +29,13 @@
 //   before the comparison, and G travels with the score — which is all the tie tolerance of
 //   xm::gt_tol needs.
 //
-// Memory: spill 8 B per cell (+4 B of scale per RS steps) instead of 12 B per cell; no row table in
-// LDS (lane3_kernel prepares per-sweep lane records, a lane fetches its next row one row ahead into
-// registers), so 9.5 KB of LDS and 126 VGPRs give 16 waves per CU.  Launch: reads are handed to the
-// persistent waves longest first (launch_order); reads whose skew exceeds ALIGN1_C_CAP run in a
-// second launch with larger rings and a longer rescale period.
+// Memory: spill 8 B per cell (+4 B of scale per RS steps) instead of 12 B per cell; no row table in LDS
+// (lane3_kernel prepares per-sweep lane records, a lane fetches the record of its next row through the scalar
+// cache when it switches rows), so 9.5 KB of LDS per wave.  Launches (launch_align3): the reverse sweeps of all
+// reads of a chunk, then their forward sweeps (template parameter PHASE: 73 and 115 registers, 24 and 16
+// waves per CU), every read with a spill slot of its own; reads are handed to the persistent waves longest
+// first (launch_order); reads whose band is too wide for one wave's rings (skew above ALIGN1_C_CAP) are swept
+// by teams of four waves (template parameter W, ReadMeta::cw) in a second pair of launches.
 //
 // Time mapping: cell (r, i) is computed at step t = i + off[r] with the planner's per-row offsets
 // (RowParam::off, kernels_plan.hip) instead of one skew per read; a lane record carries the age of the
@@ -49,10 +51,14 @@
 // outside the band, so the posterior is; no vector address arithmetic for the spill (buffer resource:
 // scalar step offset + constant lane offset) or for the history ring (read index advanced per lane,
 // write address = scalar slot base + constant lane offset); the emission product's row-type select is
-// one FMA with per-row constants; uniform conditions live in scalar registers.  Tried and not kept:
-// 16 or 4 forward steps per loop trip (instruction cache / prefetch depth), the sample of the next
-// density read one step earlier (-0.7 %, but 4 more registers: over 128 with the FMA constants),
-// update bits shifted in with v_addc (inline assembly blocks the scheduler: +1 %).
+// one FMA with per-row constants; uniform conditions live in scalar registers; no loop end tests (the step
+// count is a multiple of 32) and, with 16 steps per loop trip and the compiled-in rescale period of 16, no
+// test on the step's position in the period; the two rare cases "first row" / "last row" behind one scalar
+// test; the signal ring's refill loaded one chunk ahead; no density re-evaluation at a row switch (the
+// planner keeps the lane idle for the steps on which stale densities pass).  Tried and not kept (DESIGN.md
+// 5.1 has the measurements): 32 forward steps per trip (128 registers), the sample of the next density read
+// one step earlier, update bits shifted in with v_addc, the history-ring read pipelined one step ahead with
+// age-1 values by DPP, lane records prefetched into L2, 5 waves per SIMD in the forward sweep.
 #include <math.h>
 
 #include <new>
