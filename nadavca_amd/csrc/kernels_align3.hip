@@ -363,9 +363,11 @@ struct Scale {
 #define NVK_LB 4
 #endif
 #ifndef NVK_LB_REV
-#define NVK_LB_REV 6
+#define NVK_LB_REV 7  // (73 registers wanted, 72 allowed: two spilled ones outside the step loop; 6.45 against 6.59 ms at 6)
 #endif
-#define NVK_LB_REV_TEAM 6  // (the team's reverse sweep needs 76 registers: 80 without spills)
+#ifndef NVK_LB_REV_TEAM
+#define NVK_LB_REV_TEAM 6  // (the team's reverse sweep: 80 registers; 5 and 4 measured the same within noise)
+#endif
 //
 // W: waves per read.  1 — the mapping above.  W > 1 (wide bands: ReadMeta::cw != 0, two-launch form only) — a
 // TEAM of W waves sweeps one read with one row per lane of its TL = 64 W lanes: a lane's next row lies TL

@@ -9,7 +9,7 @@ NAME=$1; shift
 mkdir -p $ROOT/variants /tmp/vb_$NAME
 cd /tmp/vb_$NAME
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wno-unused-function \
-  -mllvm -amdgpu-sched-strategy=max-ilp ${FTZ--fdenormal-fp-math=preserve-sign} "$@" --save-temps -c ${SRC:-$C/kernels_align3.hip} -o a3.o
+  ${SCHED--mllvm -amdgpu-sched-strategy=max-ilp} ${FTZ--fdenormal-fp-math=preserve-sign} "$@" --save-temps -c ${SRC:-$C/kernels_align3.hip} -o a3.o
 API=$C/api.o
 if [ -n "$APIDEBUG" ]; then  # api.hip with the debug switches (NADAVCA_ALIGN3_NORETRY leaves flagged reads alone)
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wno-unused-function -DNVK_DEBUG_SWITCHES -c $C/api.hip -o api_dbg.o
