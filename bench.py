@@ -296,8 +296,11 @@ def main():
                         'chunk_groups': extra.get('chunks')})
         if is_align or wname == 'api_align_signal':
             cfg.update({'reads_redone_exact': stats['reads_redone_exact'],
-                        # reads in which a path comparison fell inside the tie margin (include/nadavca_hip.h)
-                        'reads_tie_ambiguous': stats['reads_tie_ambiguous']})
+                        # reads in which a path comparison fell inside the tie margin (include/nadavca_hip.h):
+                        # exactly equal scores / within 64 ulps of the reference's log value / further apart but
+                        # inside 2^-24 relative
+                        'reads_tie_exact': stats['reads_tie_exact'], 'reads_tie_ulp': stats['reads_tie_ulp'],
+                        'reads_tie_near': stats['reads_tie_near']})
         if wname == 'cfg4_consensus':
             cfg.update({'reference_length': ref_len, 'chunk_groups': extra.get('groups'),
                         'collective': 'none (1 rank)' if dist is None else 'reduce(sum) of [L,5] f64 over RCCL'})

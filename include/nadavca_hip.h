@@ -96,19 +96,37 @@ int nvk_last_batch_stats(nvk_ctx *ctx, int64_t *band_cells, int64_t *wave_steps,
  * and were recomputed by the exact kernel (results are the same either way; this is a cost figure) */
 int nvk_last_retry_count(nvk_ctx *ctx, int64_t *n_reads);
 /* PARITY CONTRACT of refine_alignment.  The reference decides every step of its path search with a strict
- * `>` between natural-log doubles (/root/reference/nadavca/dtw/node.cpp:52,72,82).  This engine computes
- * the same scores as scaled linear numbers (2^-53 relative precision) and takes `a > b` only if a exceeds
- * b by more than one ulp of the reference's log value (relative margin |exponent| * 2^-52), so that a
- * plateau the reference sees as flat — the boundary between two adjacent bases with the same k-mer level —
- * resolves to the first maximum as it does there.  Results are therefore IDENTICAL to the reference's
- * except possibly in reads where some comparison fell INSIDE that margin (there the reference's own
- * choice is decided by its rounding noise).  Such reads are counted and flagged:
- *   nvk_last_tie_count   number of reads of the last nvk_refine_alignment_batch[_dev] call in which at
- *                        least one path comparison was closer than the margin
- *   nvk_last_tie_flags   per read, nonzero = such a comparison occurred; out_flags i32[n_reads] (host),
- *                        n_reads must be that call's n_reads
- * A read with flag 0 has the reference's events exactly (tests/test_gpu_parity_full.py). */
+ * `>` between natural-log doubles (/root/reference/nadavca/dtw/node.cpp:52,72,82) that it produced with
+ * a + log(1 + exp(b - a)) (probability.cpp:33-40).  This engine computes the same scores as scaled linear
+ * numbers (2^-53 relative precision) and takes `a > b` only if a exceeds b by more than one ulp of the
+ * reference's log value (relative margin |exponent| * 2^-52, xm::gt_tol), so that a plateau the reference
+ * sees as flat resolves to the first maximum as it does there.  Every comparison whose two scores are closer
+ * than the TIE MARGIN, 2^-24 RELATIVE (NVK_TIE_BITS in csrc/xmath.h), is recorded per read, in three classes:
+ *   NVK_TIE_EXACT  the two scores are exactly equal.  Both sides resolve an exact tie the same way (no update,
+ *                  the first maximum stays).
+ *   NVK_TIE_ULP    different, but by no more than 64 of those ulp-sized margins (NVK_TIE_ULPS): the zone in
+ *                  which the reference's OWN choice can hang on the rounding of its log-doubles — a flat
+ *                  posterior plateau between two bases with the same k-mer level seen through rounding noise,
+ *                  or an ill-conditioned arg-max.
+ *   NVK_TIE_NEAR   further apart than that, still inside 2^-24 relative: both sides resolve the difference,
+ *                  kept as a safety margin around the class above.
+ * CONTRACT: a read with neither NVK_TIE_ULP nor NVK_TIE_NEAR has the reference's events exactly (asserted
+ * read by read in tests/test_gpu_parity_full.py on randomised models, wide bands, homopolymer-rich references).
+ * What the bits do NOT mean: that a flagged read differs.  Integer ADC samples repeat, so sequencer-shaped
+ * data is full of equal and almost-equal path scores — the reference's own arithmetic meets ~25 exactly equal
+ * and ~15 closer-than-2^-24 pairs of scores per config-2 read quantised to ADC steps (tests/dev/ref_tie_histogram.py)
+ * — and almost every such read carries NEAR (and most ULP) bits; yet all 10 000 of them, and all 10 000 reads of
+ * the int16 api_align_signal workload in both of align_signal's alignment passes, EQUAL the reference row for
+ * row (the same test file; rates per class in DESIGN.md 2.1).  Every difference ever observed sits in a read
+ * with the ULP bit, on a boundary between two bases with the same k-mer level or where the reference's
+ * answer changes when it is recomputed in 80-bit long double.
+ *   nvk_last_tie_count    reads of the last nvk_refine_alignment_batch[_dev] call with any bit set
+ *   nvk_last_tie_counts   the same per class (a read may carry several bits)
+ *   nvk_last_tie_flags    per read, the OR of its classes; out_flags i32[n_reads] (host), n_reads must be that
+ *                         call's n_reads */
+enum { NVK_TIE_EXACT = 1, NVK_TIE_NEAR = 2, NVK_TIE_ULP = 4 };
 int nvk_last_tie_count(nvk_ctx *ctx, int64_t *n_reads);
+int nvk_last_tie_counts(nvk_ctx *ctx, int64_t *n_exact, int64_t *n_near, int64_t *n_ulp);
 int nvk_last_tie_flags(nvk_ctx *ctx, int64_t n_reads, int32_t *out_flags);
 /* Cap, in bytes, on the device memory the sweep kernels take for their per-wave spill (the suffix rows of
  * the reads in flight: 512 B per wavefront step and resident wave).  0 (default): up to 60 % of the memory

@@ -23,6 +23,10 @@ READ_BAD_INPUT = -1
 READ_BAD_BAND = -2
 READ_TOO_WIDE = -3
 
+TIE_EXACT = 1   # nvk_last_tie_flags: some path comparison of the read met two exactly equal scores
+TIE_NEAR = 2    # ... two scores closer than 2^-24 relative (beyond the class below)
+TIE_ULP = 4     # ... two scores within 64 ulps of the reference's log value, not equal (where its rounding may decide)
+
 K_PLAN, K_ALIGN, K_ELL_SWEEP, K_ELL_HYP, K_EXPECTED, K_CONSENSUS, K_POSTERIOR, K_RENORM = range(8)
 KERNEL_NAMES = ['plan', 'align', 'ell_sweep', 'ell_hyp', 'expected', 'consensus', 'posterior', 'renorm']
 
@@ -46,6 +50,7 @@ SIGNATURES = {
     'nvk_last_batch_stats': (_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     'nvk_last_retry_count': (_int, [_vp, C.POINTER(_i64)]),
     'nvk_last_tie_count': (_int, [_vp, C.POINTER(_i64)]),
+    'nvk_last_tie_counts': (_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     'nvk_last_tie_flags': (_int, [_vp, _i64, _vp]),
     'nvk_ctx_set_workspace_limit': (_int, [_vp, _i64]),
     'nvk_model_create': (_int, [_vp, _int, _int, _int, _vp, _vp, _i64, C.POINTER(_vp)]),
@@ -159,12 +164,15 @@ class Context:
         check(self._lib.nvk_last_retry_count(self.handle, C.byref(d)), 'nvk_last_retry_count')
         e = _i64()
         check(self._lib.nvk_last_tie_count(self.handle, C.byref(e)), 'nvk_last_tie_count')
+        f, g, h = _i64(), _i64(), _i64()
+        check(self._lib.nvk_last_tie_counts(self.handle, C.byref(f), C.byref(g), C.byref(h)), 'nvk_last_tie_counts')
         return dict(band_cells=a.value, wave_steps=b.value, spill_bytes=c.value, reads_redone_exact=d.value,
-                    reads_tie_ambiguous=e.value)
+                    reads_tie_ambiguous=e.value, reads_tie_exact=f.value, reads_tie_near=g.value,
+                    reads_tie_ulp=h.value)
 
     def last_tie_flags(self, n_reads):
-        """Per read of the last refine_alignment batch: nonzero where a path comparison fell inside the
-        tolerance band (include/nadavca_hip.h, parity contract)."""
+        """Per read of the last refine_alignment batch: TIE_EXACT | TIE_NEAR | TIE_ULP where a path comparison fell
+        inside the tie margin (include/nadavca_hip.h, parity contract)."""
         import numpy as np
         out = np.zeros(int(n_reads), dtype=np.int32)
         check(self._lib.nvk_last_tie_flags(self.handle, int(n_reads), _vp(out.ctypes.data)), 'nvk_last_tie_flags')

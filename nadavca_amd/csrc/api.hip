@@ -10,6 +10,7 @@
 #include <new>
 #include <vector>
 
+#include "variant_switches.h"
 #include "nvk_internal.h"
 
 static thread_local char g_err[512] = "";
@@ -56,15 +57,17 @@ int nvk_ws_reserve(nvk_ctx *ctx, int which, size_t bytes) {
 int64_t nvk_spill_cap(nvk_ctx *ctx, int which_ws) {
   if (ctx->ws_limit > 0) return ctx->ws_limit;  // nvk_ctx_set_workspace_limit
   // default: up to 60 % of what is free on the device beyond what this workspace already holds (long
-  // reads: one resident wave spills steps * 512 B, 170 MB for a 52 k-sample read with bandwidth 1000),
-  // and never less than 48 GB worth
-  int64_t cap = (int64_t)48 << 30;
+  // reads: one read's spill is steps * 512 B, 170 MB for a 52 k-sample read with bandwidth 1000); a lane of
+  // the pipelined host path (pipeline.hip) takes its share of that.  No floor beyond one read's worth: when
+  // little is free (other tensors, another process on the GPU) the chunker serves fewer reads per launch,
+  // and launch_align3 halves a chunk whose allocation still fails.
+  const int share = ctx->spill_share > 1 ? ctx->spill_share : 1;
+  int64_t cap = ((int64_t)48 << 30) / share;  // (if the runtime cannot say what is free)
   size_t free_b = 0, total_b = 0;
-  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-    const int64_t avail = (int64_t)((double)(free_b + ctx->ws_bytes[which_ws]) * 0.6);
-    if (avail > cap) cap = avail;
-  }
-  return cap;
+  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+    cap = (int64_t)((double)(free_b + ctx->ws_bytes[which_ws]) * 0.6 / share);
+  const int64_t floor_b = (int64_t)64 << 20;
+  return cap > floor_b ? cap : floor_b;
 }
 
 TimerScope::TimerScope(nvk_ctx *c, int kid) : ctx(c), id(kid) {
@@ -128,6 +131,7 @@ extern "C" int nvk_ctx_create(int device, nvk_ctx **out) {
 extern "C" void nvk_ctx_destroy(nvk_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
+  nvk_pipe_release(ctx);  // the lanes of the pipelined host path (threads, their contexts and staging)
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
   for (int i = 0; i < WS_COUNT; i++)
@@ -198,6 +202,14 @@ extern "C" int nvk_last_tie_count(nvk_ctx *ctx, int64_t *n_reads) {
   return NVK_OK;
 }
 
+extern "C" int nvk_last_tie_counts(nvk_ctx *ctx, int64_t *n_exact, int64_t *n_near, int64_t *n_ulp) {
+  if (!ctx) return NVK_ERR_INVALID;
+  if (n_exact) *n_exact = ctx->last_ties_exact;
+  if (n_near) *n_near = ctx->last_ties_near;
+  if (n_ulp) *n_ulp = ctx->last_ties_ulp;
+  return NVK_OK;
+}
+
 extern "C" int nvk_last_tie_flags(nvk_ctx *ctx, int64_t n_reads, int32_t *out_flags) {
   if (!ctx || !out_flags || n_reads < 0) return NVK_ERR_INVALID;
   if (n_reads != ctx->ties_n) {
@@ -206,6 +218,7 @@ extern "C" int nvk_last_tie_flags(nvk_ctx *ctx, int64_t n_reads, int32_t *out_fl
     return NVK_ERR_INVALID;
   }
   if (n_reads == 0) return NVK_OK;
+  if (nvk_pipe_tie_flags(ctx, n_reads, out_flags)) return NVK_OK;  // the last call came through pipeline.hip
   NVK_HIP(hipSetDevice(ctx->device));
   NVK_HIP(hipMemcpyAsync(out_flags, ctx->ws[WS_TIES], (size_t)n_reads * sizeof(int32_t), hipMemcpyDeviceToHost,
                          ctx->stream));
@@ -216,6 +229,7 @@ extern "C" int nvk_last_tie_flags(nvk_ctx *ctx, int64_t n_reads, int32_t *out_fl
 extern "C" int nvk_ctx_set_workspace_limit(nvk_ctx *ctx, int64_t bytes) {
   if (!ctx || bytes < 0) return NVK_ERR_INVALID;
   ctx->ws_limit = bytes;
+  nvk_pipe_set_ws_limit(ctx, bytes);
   return NVK_OK;
 }
 
@@ -541,11 +555,12 @@ extern "C" int nvk_refine_alignment_batch_dev(
   //   NADAVCA_ALIGN_KERNEL=1   kernels_align.hip only (mantissa+exponent per value)
   const char *force = getenv("NADAVCA_ALIGN_KERNEL");
   ctx->last_retries = 0;
-  ctx->last_ties = 0;
+  ctx->last_ties = ctx->last_ties_exact = ctx->last_ties_near = ctx->last_ties_ulp = 0;
+  nvk_pipe_forget_ties(ctx);
   rc = plan_batch(model, a, model_transitions ? PLAN_ALIGN_TRANS : PLAN_ALIGN_PLAIN, 0, tot);
   if (rc) return rc;
-  if ((rc = nvk_ws_reserve(ctx, WS_TIES, (size_t)(n_reads + 1) * sizeof(int32_t)))) return rc;
-  NVK_HIP(hipMemsetAsync(ctx->ws[WS_TIES], 0, (size_t)(n_reads + 1) * sizeof(int32_t), ctx->stream));
+  if ((rc = nvk_ws_reserve(ctx, WS_TIES, (size_t)(n_reads + 8) * sizeof(int32_t)))) return rc;
+  NVK_HIP(hipMemsetAsync(ctx->ws[WS_TIES], 0, (size_t)(n_reads + 8) * sizeof(int32_t), ctx->stream));
   ctx->ties_n = n_reads;
   const ReadMeta *metas = (const ReadMeta *)ctx->ws[WS_META];
   const RowParam *rows = (const RowParam *)ctx->ws[WS_ROWS];
@@ -573,47 +588,16 @@ extern "C" int nvk_refine_alignment_batch_dev(
   }
   {  // reads in which a path decision fell inside the comparison tolerance (include/nadavca_hip.h)
     int32_t *d_ties = (int32_t *)ctx->ws[WS_TIES];
-    int32_t n_ties = 0;
+    int32_t n_ties[4] = {0, 0, 0, 0};
     rc = launch_count_flags(ctx, d_ties, n_reads, d_ties + n_reads);
     if (rc) return rc;
-    NVK_HIP(hipMemcpyAsync(&n_ties, d_ties + n_reads, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    NVK_HIP(hipMemcpyAsync(n_ties, d_ties + n_reads, sizeof n_ties, hipMemcpyDeviceToHost, ctx->stream));
     NVK_HIP(hipStreamSynchronize(ctx->stream));
-    ctx->last_ties = n_ties;
+    ctx->last_ties = n_ties[0];
+    ctx->last_ties_exact = n_ties[1];
+    ctx->last_ties_near = n_ties[2];
+    ctx->last_ties_ulp = n_ties[3];
   }
-  NVK_HIP(hipStreamSynchronize(ctx->stream));
-  return NVK_OK;
-}
-
-extern "C" int nvk_refine_alignment_batch(nvk_model *model, int64_t n_reads, const double *signal,
-                                          const int64_t *sig_off, const int32_t *reference,
-                                          const int64_t *ref_off, const int32_t *ctx_before,
-                                          const int64_t *cb_off, const int32_t *ctx_after,
-                                          const int64_t *ca_off, const int32_t *anchors,
-                                          const int64_t *anc_off, int bandwidth,
-                                          int min_event_length, int model_transitions,
-                                          int32_t *out_events, int32_t *out_status) {
-  int rc = check_common(model, n_reads, bandwidth, min_event_length);
-  if (rc) return rc;
-  if (n_reads == 0) return NVK_OK;
-  nvk_ctx *ctx = model->ctx;
-  NVK_HIP(hipSetDevice(ctx->device));
-  StagedBatch sb;
-  rc = stage_batch(ctx, n_reads, signal, sig_off, reference, ref_off, ctx_before, cb_off, ctx_after,
-                   ca_off, anchors, anc_off, bandwidth, min_event_length, true, sb);
-  if (rc) return rc;
-  DevBuf d_ev, d_st;
-  size_t evb = (size_t)sb.a.total_ref * 2 * 4, stb = (size_t)n_reads * 4;
-  if ((rc = d_ev.alloc(evb))) return rc;
-  if ((rc = d_st.alloc(stb))) return rc;
-  NVK_HIP(hipMemsetAsync(d_ev.p, 0, evb ? evb : 16, ctx->stream));
-  rc = nvk_refine_alignment_batch_dev(
-      model, n_reads, sb.a.total_signal, sb.a.total_ref, sb.a.total_anchors, sb.a.signal,
-      sb.a.sig_off, sb.a.reference, sb.a.ref_off, sb.a.ctx_before, sb.a.cb_off, sb.a.ctx_after,
-      sb.a.ca_off, sb.a.anchors, sb.a.anc_off, bandwidth, min_event_length, model_transitions,
-      (int32_t *)d_ev.p, (int32_t *)d_st.p);
-  if (rc) return rc;
-  if (evb) NVK_HIP(hipMemcpyAsync(out_events, d_ev.p, evb, hipMemcpyDeviceToHost, ctx->stream));
-  NVK_HIP(hipMemcpyAsync(out_status, d_st.p, stb, hipMemcpyDeviceToHost, ctx->stream));
   NVK_HIP(hipStreamSynchronize(ctx->stream));
   return NVK_OK;
 }
@@ -686,39 +670,6 @@ extern "C" int nvk_estimate_log_likelihoods_batch_dev(
   ctx->last_steps = (int64_t)tot.steps;
   rc = launch_ell(ctx, model->dm, a, model_wobbling ? 1 : 0, pl, tot, out_ll, out_status);
   if (rc) return rc;
-  NVK_HIP(hipStreamSynchronize(ctx->stream));
-  return NVK_OK;
-}
-
-extern "C" int nvk_estimate_log_likelihoods_batch(
-    nvk_model *model, int64_t n_reads, const double *signal, const int64_t *sig_off,
-    const int32_t *reference, const int64_t *ref_off, const int32_t *ctx_before,
-    const int64_t *cb_off, const int32_t *ctx_after, const int64_t *ca_off,
-    const int32_t *anchors, const int64_t *anc_off, int bandwidth, int min_event_length,
-    int model_wobbling, double *out_ll, int32_t *out_status) {
-  int rc = check_common(model, n_reads, bandwidth, min_event_length);
-  if (rc) return rc;
-  if (n_reads == 0) return NVK_OK;
-  nvk_ctx *ctx = model->ctx;
-  NVK_HIP(hipSetDevice(ctx->device));
-  StagedBatch sb;
-  rc = stage_batch(ctx, n_reads, signal, sig_off, reference, ref_off, ctx_before, cb_off, ctx_after,
-                   ca_off, anchors, anc_off, bandwidth, min_event_length, true, sb);
-  if (rc) return rc;
-  const int alpha = model->dm.alphabet;
-  DevBuf d_ll, d_st;
-  size_t llb = (size_t)sb.a.total_ref * alpha * 8, stb = (size_t)n_reads * 4;
-  if ((rc = d_ll.alloc(llb))) return rc;
-  if ((rc = d_st.alloc(stb))) return rc;
-  NVK_HIP(hipMemsetAsync(d_ll.p, 0, llb ? llb : 16, ctx->stream));
-  rc = nvk_estimate_log_likelihoods_batch_dev(
-      model, n_reads, sb.a.total_signal, sb.a.total_ref, sb.a.total_anchors, sb.a.signal,
-      sb.a.sig_off, sb.a.reference, sb.a.ref_off, sb.a.ctx_before, sb.a.cb_off, sb.a.ctx_after,
-      sb.a.ca_off, sb.a.anchors, sb.a.anc_off, bandwidth, min_event_length, model_wobbling,
-      (double *)d_ll.p, (int32_t *)d_st.p);
-  if (rc) return rc;
-  if (llb) NVK_HIP(hipMemcpyAsync(out_ll, d_ll.p, llb, hipMemcpyDeviceToHost, ctx->stream));
-  NVK_HIP(hipMemcpyAsync(out_status, d_st.p, stb, hipMemcpyDeviceToHost, ctx->stream));
   NVK_HIP(hipStreamSynchronize(ctx->stream));
   return NVK_OK;
 }

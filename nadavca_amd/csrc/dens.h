@@ -2,6 +2,8 @@
 #pragma once
 #include <math.h>
 
+#include "variant_switches.h"
+
 namespace dens {
 
 // e(x) * 2^dshift as a plain double.  `ac`/`mc` are the reference's constants
@@ -49,7 +51,7 @@ __device__ __forceinline__ DensHalf density_begin(double x, double mean, double 
   const double kk = rint(y);
   const double gq = y - kk;
   h.ki = (int)kk;
-#if defined(NVK_ABL) && NVK_ABL == 1
+#if NVK_ABL == 1
   h.tj = 1.0;  // ablation: no table read
 #else
   h.tj = etab[h.ki & (ETN - 1)];

@@ -61,7 +61,7 @@ struct AlignArgs {
   int wide, c_cap;  // class served by this launch: skew <= c_cap (wide = 0) or above (wide = 1)
   int only_retry;   // serve only reads flagged NVK_READ_RETRY_INTERNAL by the scaled-double kernel
   int c_max;        // largest skew this launch's LDS rings hold: wider reads get NVK_READ_TOO_WIDE
-  int32_t *ties;    // per read: a path comparison fell inside the tolerance band (nvk_last_tie_flags)
+  int32_t *ties;    // per read: NVK_TIE_EXACT | NVK_TIE_NEAR (nvk_last_tie_flags)
   int32_t *out_events;
   int32_t *out_status;
 };
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(64) void align_kernel(AlignArgs g) {
     // ================= forward sweep: prefix rows, posterior, path DP, update bits =================
     X fbest = xm::zero();
     int fidx = -1;
-    bool amb = false;  // a comparison inside the tolerance band (xm::near_tol)
+    bool amb_x = false, amb_n = false, amb_u = false;  // a comparison inside the tie margin (xm::near_tol): exactly equal / near
     {
       int r = lane;
       int loaded_hi = 0;
@@ -366,14 +366,24 @@ __global__ __launch_bounds__(64) void align_kernel(AlignArgs g) {
             // posterior * running max of the previous row (node.cpp:52-91): strict '>' keeps
             // the first maximum
             const bool upd = active && xm::gt_tol(dv, best);
-            amb |= active && xm::near_tol(dv, best);
+            {
+              const bool nr = active && xm::near_tol(dv, best), zr = xm::eq(dv, best), ur = xm::within_ulps(dv, best);
+              amb_x |= nr && zr;
+              amb_u |= nr && ur && !zr;
+              amb_n |= nr && !ur && !zr;
+            }
             best = xm::sel(upd, dv, best);
             bits |= upd ? (1u << (u & 31)) : 0u;
             X post{o.m * cur_m[q], o.e + cur_e[q] - K};
             X dpv = is_init ? post : xm::mul(best, post);
             dpv = xm::norm(dpv);
             dpv = xm::sel(in_band, dpv, xm::zero());
-            amb |= (r == top) && xm::near_tol(dpv, fbest);
+            {
+              const bool nr = (r == top) && xm::near_tol(dpv, fbest), zr = xm::eq(dpv, fbest), ur = xm::within_ulps(dpv, fbest);
+              amb_x |= nr && zr;
+              amb_u |= nr && ur && !zr;
+              amb_n |= nr && !ur && !zr;
+            }
             if (r == top && xm::gt_tol(dpv, fbest)) {
               fbest = dpv;
               fidx = i;
@@ -411,7 +421,11 @@ __global__ __launch_bounds__(64) void align_kernel(AlignArgs g) {
       if (lane == 0) g.out_status[rd] = NVK_READ_NO_PATH;
       continue;
     }
-    if (__any(amb) && lane == 0) g.ties[rd] = 1;
+    {
+      const bool ax = __any(amb_x), an = __any(amb_n), au = __any(amb_u);
+      if ((ax || an || au) && lane == 0)
+        g.ties[rd] = (ax ? NVK_TIE_EXACT : 0) | (an ? NVK_TIE_NEAR : 0) | (au ? NVK_TIE_ULP : 0);
+    }
     if (lane == 0) {
       int32_t *ev = g.out_events + 2 * m.ref_off;
       int st = NVK_READ_OK;

@@ -64,19 +64,10 @@
 #include <new>
 #include <vector>
 
+#include "variant_switches.h"
 #include "nvk_internal.h"
 #include "xmath.h"
 #include "dens.h"
-
-#ifndef NVK_ABL
-#define NVK_ABL 0  // ablation experiments (timing only, results are wrong): see tools/README.md
-#endif
-#ifndef NVK_NO_TIEFLAG
-#define NVK_NO_TIEFLAG 0  // (development switch: what the tie flag costs)
-#endif
-#ifndef NVK_PAIR_DEBUG
-#define NVK_PAIR_DEBUG 0  // 1: paired arithmetic, but every lane evaluates its own density at every step
-#endif
 
 namespace {
 
@@ -123,6 +114,9 @@ constexpr int TARGET = 250; // exponent the largest live value is moved to
 #define NVK_TIE_BITS 24
 #endif
 #define TIE_FLAG_REL (1.0 / (double)(1ull << NVK_TIE_BITS))  // relative margin of the tie flag (xmath.h: near_tol)
+#ifndef NVK_TIE_ULPS
+#define NVK_TIE_ULPS 64  // NVK_TIE_ULP: the two scores differ by at most this many margins of xm::gt_tol (~ ulps of the log value)
+#endif
 
 // The spill is addressed through a buffer resource: address = resource base (scalar) + scalar byte
 // offset of the step + per-lane byte offset (a constant vector register), so neither the store of the
@@ -212,7 +206,7 @@ struct Align3Args {
   int read_lo;       // two-launch mode: positions [read_lo, read_lo + n_reads) of `order` are served, the spill of
                      // position p lives in slot p - read_lo
   int *n_retry;      // reads handed to the exact kernel
-  int32_t *ties;     // per read: a path comparison fell inside the tolerance band (nvk_last_tie_flags)
+  int32_t *ties;     // per read: NVK_TIE_EXACT | NVK_TIE_NEAR — a path comparison fell inside the tie margin (nvk_last_tie_flags)
   int32_t *out_events;
   int32_t *out_status;
 };
@@ -776,7 +770,10 @@ __global__ __launch_bounds__(64 * W, PHASE == 1 ? (W > 1 ? NVK_LB_REV_TEAM : NVK
     // and written by the last row's lane only, it cost 4 % — one more LDS round trip on that row's steps)
     double fbest = 0.0, fthr = 0.0;
     int fidx = -1, fG = 0;
-    unsigned long long amb = 0;  // (scalar) lanes that saw a comparison inside the tolerance band
+    // (scalar) lanes that saw a comparison inside the tie margin, by class (include/nadavca_hip.h): the two scores
+    // exactly equal (amb_x), different but within NVK_TIE_ULPS margins of xm::gt_tol — ulps of the reference's
+    // log value, where its own rounding may decide — (amb_u), beyond that but inside 2^-24 relative (amb_n)
+    unsigned long long amb_x = 0, amb_u = 0, amb_n = 0;
     {
       int r = gl;
       // Lanes without a row keep lo = be = +big: never active, never finished.  For the other rows
@@ -1010,7 +1007,17 @@ __global__ __launch_bounds__(64 * W, PHASE == 1 ? (W > 1 ? NVK_LB_REV_TEAM : NVK
             // the path would tie by their lost precision: this file is compiled with FP64 denormals
             // flushed, which makes them exact zeros.)
 #if !NVK_NO_TIEFLAG
-            amb |= __builtin_amdgcn_ballot_w64(fabs(tdiff) < dva * TIE_FLAG_REL);
+            {
+              const unsigned long long nr = __builtin_amdgcn_ballot_w64(fabs(tdiff) < dva * TIE_FLAG_REL);
+              if (nr != 0) {  // (rare, a scalar branch: the classes are sorted out off the usual path)
+                asm volatile("");
+                const unsigned long long zr = __builtin_amdgcn_ballot_w64(tdiff == 0.0);
+                const unsigned long long ur = __builtin_amdgcn_ballot_w64(fabs(tdiff) <= bthr * (double)NVK_TIE_ULPS);
+                amb_x |= nr & zr;
+                amb_u |= nr & ur & ~zr;
+                amb_n |= nr & ~ur & ~zr;
+              }
+            }
 #endif
             if (upd) {
               bestn = __builtin_amdgcn_frexp_mant(dv);         // in [0.5, 1)
@@ -1031,7 +1038,17 @@ __global__ __launch_bounds__(64 * W, PHASE == 1 ? (W > 1 ? NVK_LB_REV_TEAM : NVK
               }
               if (top_live) {
               const double da = ldexp(dpv, (fbest == 0.0) ? 0 : fG - Gd);
-              amb |= __builtin_amdgcn_ballot_w64(r == top && IN_BAND && fabs(da - fbest) < da * TIE_FLAG_REL);
+              {
+                const unsigned long long nr = __builtin_amdgcn_ballot_w64(r == top && IN_BAND && fabs(da - fbest) < da * TIE_FLAG_REL);
+                if (nr != 0) {
+                  asm volatile("");
+                  const unsigned long long zr = __builtin_amdgcn_ballot_w64(da == fbest);
+                  const unsigned long long ur = __builtin_amdgcn_ballot_w64(fabs(da - fbest) <= fthr * (double)NVK_TIE_ULPS);
+                  amb_x |= nr & zr;
+                  amb_u |= nr & ur & ~zr;
+                  amb_n |= nr & ~ur & ~zr;
+                }
+              }
               if (r == top && IN_BAND && (da - fbest > fthr)) {
                 fbest = dpv;
                 fG = Gd;
@@ -1119,14 +1136,16 @@ __global__ __launch_bounds__(64 * W, PHASE == 1 ? (W > 1 ? NVK_LB_REV_TEAM : NVK
     int idx = __shfl(fidx, top & 63, 64);
     bool any_suspect = __any(suspect);
     if (W > 1) {  // the team's verdict: any wave's range guard or tie flag, the arg-max of the wave that held `top`
-      if (lane == 0) tflag[wv] = (any_suspect ? 1 : 0) | (amb != 0 ? 2 : 0);
+      if (lane == 0) tflag[wv] = (any_suspect ? 1 : 0) | (amb_x != 0 ? 2 : 0) | (amb_n != 0 ? 4 : 0) | (amb_u != 0 ? 8 : 0);
       if (gl == (top & (TL - 1))) *tfidx = fidx;
       __syncthreads();
       int fl = 0;
 #pragma unroll
       for (int w = 0; w < W; w++) fl |= tflag[w];
       any_suspect = (fl & 1) != 0;
-      amb = (fl & 2) ? 1ull : 0ull;
+      amb_x = (fl & 2) ? 1ull : 0ull;
+      amb_n = (fl & 4) ? 1ull : 0ull;
+      amb_u = (fl & 8) ? 1ull : 0ull;
       idx = *tfidx;
     }
     if (any_suspect || (idx < 0 && K != 0)) {
@@ -1141,7 +1160,8 @@ __global__ __launch_bounds__(64 * W, PHASE == 1 ? (W > 1 ? NVK_LB_REV_TEAM : NVK
       if (gl == 0) g.out_status[rd] = NVK_READ_NO_PATH;
       continue;
     }
-    if (gl == 0 && amb != 0) g.ties[rd] = 1;
+    if (gl == 0 && (amb_x | amb_n | amb_u) != 0)
+      g.ties[rd] = (amb_x != 0 ? NVK_TIE_EXACT : 0) | (amb_n != 0 ? NVK_TIE_NEAR : 0) | (amb_u != 0 ? NVK_TIE_ULP : 0);
     if (gl == 0) {
       int32_t *ev = g.out_events + 2 * m.ref_off;
       int st = NVK_READ_OK;
@@ -1217,12 +1237,6 @@ int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadM
   // kernels: [0] both sweeps in one wave, [1] reverse sweeps, [2] forward sweeps; rescale period 16
   // compiled in (k16) or taken from the arguments (kv).  With transition rows: the paired variant (one
   // density evaluation per lane pair and step).
-#ifndef NVK_NO_PAIR
-#define NVK_NO_PAIR 0  // (development switch, tools/build_variant.sh -DNVK_NO_PAIR=1)
-#endif
-#ifndef NVK_TWO_PHASE
-#define NVK_TWO_PHASE 1  // (development switch: 0 = the one-launch form)
-#endif
   void (*k16[3])(Align3Args) = {nullptr, nullptr, nullptr};
   void (*kv[3])(Align3Args) = {nullptr, nullptr, nullptr};
   void (*kt[3])(Align3Args) = {nullptr, nullptr, nullptr};  // teams of ALIGN3_TEAM_W waves (wide bands)
@@ -1369,21 +1383,32 @@ int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadM
         NVK_HIP(hipFuncSetAttribute((const void *)kern[ph], hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)(ph == 1 ? lds_rev : lds)));
 #if NVK_TWO_PHASE
-    // chunks of launch positions whose spill fits the cap; a chunk's slots are sized by its longest read
-    int64_t lo = 0;
-    while (lo < a.n_reads) {
+    // chunks of launch positions whose spill fits the cap; a chunk's slots are sized by its longest read.
+    // The launch order is class-major (launch_order): the teams' reads are positions [0, n_wide), the one-wave
+    // reads the rest, so a class's chunks, slots and workgroups count only the reads it sweeps.
+    const int64_t pos_lo = (W > 1) ? 0 : n_wide, pos_hi = (W > 1) ? n_wide : a.n_reads;
+    int64_t lo = pos_lo;
+    while (lo < pos_hi) {
       int64_t hi = lo, mx = 1;
-      while (hi < a.n_reads) {
+      while (hi < pos_hi) {
         const int64_t m2 = steps_sorted[(size_t)hi] > mx ? steps_sorted[(size_t)hi] : mx;
         if (hi > lo && (m2 + 2 * PF) * 512 * W * (hi - lo + 1) > cap) break;
         mx = m2;
         ++hi;
       }
-      const int64_t n_chunk = hi - lo;
-      const int64_t spill_stride = (mx + 2 * PF) * 64;
-      const int64_t L_stride = (mx >> rsh) + 4;
-      rc = nvk_ws_reserve(ctx, WS_SPILL, (size_t)n_chunk * W * spill_stride * 8);
+      int64_t n_chunk = hi - lo;
+      int64_t spill_stride = (mx + 2 * PF) * 64;
+      // (the cap is an estimate of what is free: if the allocation still fails, serve half as many reads)
+      while ((rc = nvk_ws_reserve(ctx, WS_SPILL, (size_t)n_chunk * W * spill_stride * 8)) == NVK_ERR_NOMEM &&
+             n_chunk > 1) {
+        n_chunk = (n_chunk + 1) / 2;
+        hi = lo + n_chunk;
+        mx = 1;
+        for (int64_t q = lo; q < hi; q++) mx = steps_sorted[(size_t)q] > mx ? steps_sorted[(size_t)q] : mx;
+        spill_stride = (mx + 2 * PF) * 64;
+      }
       if (rc) return rc;
+      const int64_t L_stride = (mx >> rsh) + 4;
       rc = nvk_ws_reserve(ctx, WS_STAGE, (size_t)n_chunk * L_stride * 4);
       if (rc) return rc;
       int64_t slots_f = ctx->slots_override > 0 ? ctx->slots_override : (int64_t)ctx->num_cus * per_cu;

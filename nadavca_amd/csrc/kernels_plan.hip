@@ -617,45 +617,64 @@ __global__ void expected_kernel(DeviceModel dm, int64_t n_reads, int64_t total_r
 // out longest first (64 buckets of the step count, descending, original order inside a bucket up
 // to the race of the fill) bounds that tail by the shortest reads instead.
 // ---------------------------------------------------------------------------------------------
-constexpr int ORD_B = 64;
+constexpr int ORD_B = 64;        // step-count buckets per launch class
+constexpr int ORD_N = 2 * ORD_B;  // two classes: reads swept by teams of waves first, then the one-wave reads
+// Class-major: each class of launch_align3 then serves one contiguous range of launch positions, so its chunks,
+// spill slots and workgroups count only the reads it sweeps (a few wide reads in a batch of narrow ones used
+// to cost every read a team-sized slot).  Reads without a plan (bad input / band) go last.
 __device__ __forceinline__ int order_bucket(const ReadMeta &m, int max_steps) {
-  if (m.status != NVK_READ_OK) return ORD_B - 1;
+  if (m.status != NVK_READ_OK) return ORD_N - 1;
   long long b = (long long)m.n_steps * ORD_B / ((long long)max_steps + 1);
-  return ORD_B - 1 - (int)(b < 0 ? 0 : (b > ORD_B - 1 ? ORD_B - 1 : b));
+  const int sb = ORD_B - 1 - (int)(b < 0 ? 0 : (b > ORD_B - 1 ? ORD_B - 1 : b));
+  return (m.cw != 0 ? 0 : ORD_B) + sb;
 }
 __global__ void order_count_kernel(const ReadMeta *metas, int n, int max_steps, int *cnt) {
   int rd = blockIdx.x * blockDim.x + threadIdx.x;
   if (rd < n) atomicAdd(&cnt[order_bucket(metas[rd], max_steps)], 1);
 }
-__global__ void order_scan_kernel(int *cnt) {  // one wave: cnt[b] -> first position of bucket b; cnt[64+b] = 0
+__global__ void order_scan_kernel(int *cnt) {  // one wave, two buckets per lane: cnt[b] -> first position of bucket b; cnt[ORD_N+b] = 0
   int lane = threadIdx.x;
-  int v = cnt[lane], s = v;
+  int v0 = cnt[2 * lane], v1 = cnt[2 * lane + 1], s = v0 + v1;
   for (int d = 1; d < 64; d <<= 1) {
     int o = __shfl_up(s, d, 64);
     if (lane >= d) s += o;
   }
-  cnt[lane] = s - v;
-  cnt[ORD_B + lane] = 0;
+  cnt[2 * lane] = s - v0 - v1;
+  cnt[2 * lane + 1] = s - v1;
+  cnt[ORD_N + 2 * lane] = 0;
+  cnt[ORD_N + 2 * lane + 1] = 0;
 }
 __global__ void order_fill_kernel(const ReadMeta *metas, int n, int max_steps, int *cnt, int *order) {
   int rd = blockIdx.x * blockDim.x + threadIdx.x;
   if (rd < n) {
     int b = order_bucket(metas[rd], max_steps);
-    order[cnt[b] + atomicAdd(&cnt[ORD_B + b], 1)] = rd;
+    order[cnt[b] + atomicAdd(&cnt[ORD_N + b], 1)] = rd;
   }
 }
 
 __global__ void count_flags_kernel(const int32_t *flags, int64_t n, int32_t *out) {
   int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int v = (g < n && flags[g] != 0) ? 1 : 0;
-  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-  if ((threadIdx.x & 63) == 0 && v) atomicAdd(out, v);
+  const int f = (g < n) ? flags[g] : 0;
+  // (three counts of at most 2^20 each would fit one word; kept apart for n up to 2^31)
+  int v = (f != 0) ? 1 : 0, v0 = f & 1, v1 = (f >> 1) & 1, v2 = (f >> 2) & 1;
+  for (int d = 32; d >= 1; d >>= 1) {
+    v += __shfl_xor(v, d, 64);
+    v0 += __shfl_xor(v0, d, 64);
+    v1 += __shfl_xor(v1, d, 64);
+    v2 += __shfl_xor(v2, d, 64);
+  }
+  if ((threadIdx.x & 63) == 0 && v) {
+    atomicAdd(out, v);
+    if (v0) atomicAdd(out + 1, v0);
+    if (v1) atomicAdd(out + 2, v1);
+    if (v2) atomicAdd(out + 3, v2);
+  }
 }
 
 }  // namespace
 
 int launch_count_flags(nvk_ctx *ctx, const int32_t *flags, int64_t n, int32_t *out_count) {
-  NVK_HIP(hipMemsetAsync(out_count, 0, sizeof(int32_t), ctx->stream));
+  NVK_HIP(hipMemsetAsync(out_count, 0, 4 * sizeof(int32_t), ctx->stream));
   if (n <= 0) return NVK_OK;
   hipLaunchKernelGGL(count_flags_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, flags, n,
                      out_count);
@@ -667,11 +686,11 @@ int launch_count_flags(nvk_ctx *ctx, const int32_t *flags, int64_t n, int32_t *o
 int launch_order(nvk_ctx *ctx, const ReadMeta *metas, int64_t n_reads, int max_steps, int **order) {
   *order = nullptr;
   if (n_reads <= 0) return NVK_OK;
-  int rc = nvk_ws_reserve(ctx, WS_ORDER, (size_t)n_reads * sizeof(int) + 2 * ORD_B * sizeof(int));
+  int rc = nvk_ws_reserve(ctx, WS_ORDER, (size_t)n_reads * sizeof(int) + 2 * ORD_N * sizeof(int));
   if (rc) return rc;
   int *ord = (int *)ctx->ws[WS_ORDER];
   int *cnt = ord + n_reads;
-  NVK_HIP(hipMemsetAsync(cnt, 0, 2 * ORD_B * sizeof(int), ctx->stream));
+  NVK_HIP(hipMemsetAsync(cnt, 0, 2 * ORD_N * sizeof(int), ctx->stream));
   const unsigned blocks = (unsigned)((n_reads + 255) / 256);
   TimerScope ts(ctx, NVK_K_PLAN);
   hipLaunchKernelGGL(order_count_kernel, dim3(blocks), dim3(256), 0, ctx->stream, metas, (int)n_reads, max_steps, cnt);

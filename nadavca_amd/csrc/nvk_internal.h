@@ -93,9 +93,12 @@ struct nvk_ctx {
   // stats of the last batch
   int64_t last_cells, last_steps, last_spill_bytes;
   int64_t last_retries;  // reads of the last refine batch redone by the exact kernel
-  int64_t last_ties;     // reads of the last refine batch with a path decision inside the tolerance band
+  int64_t last_ties;     // reads of the last refine batch with a path decision inside the tie margin
+  int64_t last_ties_exact, last_ties_near, last_ties_ulp;  // ... per class (NVK_TIE_EXACT / _NEAR / _ULP)
   int64_t ties_n;        // number of reads ws[WS_TIES] describes
   int64_t ws_limit;      // nvk_ctx_set_workspace_limit: cap on the sweep kernels' spill workspace (0 = default)
+  int spill_share;       // > 1: this ctx is one of that many lanes of a pipelined host path sharing the device
+  struct nvk_pipe_state *pipe;  // lanes of the pipelined host-pointer entry points (pipeline.hip), made on first use
 };
 
 struct nvk_model {
@@ -106,6 +109,11 @@ struct nvk_model {
 
 
 void nvk_set_error(const char *fmt, ...);
+// pipeline.hip
+void nvk_pipe_release(nvk_ctx *ctx);
+int nvk_pipe_tie_flags(nvk_ctx *ctx, int64_t n_reads, int32_t *out_flags);
+void nvk_pipe_forget_ties(nvk_ctx *ctx);
+void nvk_pipe_set_ws_limit(nvk_ctx *ctx, int64_t bytes);
 int nvk_ws_reserve(nvk_ctx *ctx, int which, size_t bytes);
 
 struct TimerScope {
@@ -160,7 +168,7 @@ int launch_plan_ell(nvk_ctx *ctx, const DeviceModel &dm, const BatchArgs &a, int
                     const EllPlan &pl, unsigned long long *bandtmp, PlanTotals *totals);
 int launch_ell(nvk_ctx *ctx, const DeviceModel &dm, const BatchArgs &a, int wobbling,
                const EllPlan &pl, const PlanTotals &tot, double *out_ll, int32_t *out_status);
-// *out_count = number of nonzero entries of flags[0..n)
+// out_count[0..4) = number of entries of flags[0..n) that are nonzero / have bit 0 / bit 1 / bit 2 set
 int launch_count_flags(nvk_ctx *ctx, const int32_t *flags, int64_t n, int32_t *out_count);
 // bytes the resident waves' spill may take: the ctx limit if set, else a default share of the free memory
 int64_t nvk_spill_cap(nvk_ctx *ctx, int which_ws);

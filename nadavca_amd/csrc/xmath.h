@@ -16,6 +16,9 @@
 #ifndef NVK_TIE_BITS
 #define NVK_TIE_BITS 24  // the tie flag's relative margin is 2^-NVK_TIE_BITS (near_tol)
 #endif
+#ifndef NVK_TIE_ULPS
+#define NVK_TIE_ULPS 64  // NVK_TIE_ULP: scores closer than this many margins of gt_tol (~ ulps of the reference's log value)
+#endif
 
 namespace xm {
 
@@ -121,6 +124,16 @@ __device__ __forceinline__ bool gt_tol(X a, X b) {
 __device__ __forceinline__ bool near_tol(X a, X b) {
   double am = ldexp(a.m, a.e - b.e);
   return fabs(am - b.m) < am * (1.0 / (double)(1ull << NVK_TIE_BITS)) && b.m != 0.0;
+}
+
+// a == b exactly, for normalised operands or one of them shifted onto the other's exponent (scaling by a
+// power of two is exact): the "exact tie" class of the parity contract
+__device__ __forceinline__ bool eq(X a, X b) { return ldexp(a.m, a.e - b.e) == b.m; }
+
+// |a - b| within NVK_TIE_ULPS margins of gt_tol (the NVK_TIE_ULP class of the parity contract)
+__device__ __forceinline__ bool within_ulps(X a, X b) {
+  const double diff = fabs(ldexp(a.m, a.e - b.e) - b.m);
+  return diff <= b.m * ((double)abs(b.e) * 0x1.0p-52) * (double)NVK_TIE_ULPS;
 }
 
 // c ? a : b.  (gfx950 note, tools/ubench_valu.hip: a v_cndmask_b32_e32 that re-reads an unchanged

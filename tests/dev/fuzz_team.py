@@ -1,7 +1,7 @@
 """Randomised parity run aimed at the wide-band path of refine_alignment (teams of waves, kernels_align3.hip):
 bandwidths 100-700 on reads of 20-700 bases, so that most reads need a skew above the one-wave launch's cap;
 min event length 0-4, transitions on/off, random and packaged k-mer models, mixed narrow reads in the batch.
-Checks the parity contract: every read that differs from the reference carries the tie flag.
+Checks the parity contract: every read that differs from the reference carries the near-tie bit.
 usage: fuzz_team.py SECONDS [seed]"""
 import sys, time
 import numpy as np
@@ -31,7 +31,7 @@ while time.time() < t_end:
         n_nopath += int(exp.size == 0)
         if ev.shape != exp.shape or not np.array_equal(ev, exp):
             n_diff += 1
-            if not ties[ci]:
+            if not (ties[ci] & 6):   # NVK_TIE_NEAR | NVK_TIE_ULP: the contract's only escape
                 n_unflagged += 1
                 print('UNFLAGGED MISMATCH it', it - 1, 'case', ci, 'k', k, 'mel', mel, 'bw', bw, 'tr', tr, 'R', len(c['reference']),
                       'N', len(c['signal']), 'shapes', ev.shape, exp.shape, flush=True)

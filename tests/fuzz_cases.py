@@ -58,3 +58,42 @@ def make_team_batch(seed0, it):
 def reads_of(cases):
     return [(c['signal'], c['reference'], c['context_before'], c['context_after'], c['approximate_alignment'])
             for c in cases]
+
+
+def classify_difference(ev, exp, case, fb_model, k, central, alphabet, bw, mel, tr, referee=None):
+    """Why do the engine's rows ``ev`` differ from the double-precision reference's ``exp`` on this read?
+    -> one of 'flat-plateau' (every differing boundary lies between two bases with the SAME k-mer level: the
+    posterior is exactly flat there and any rounding decides), 'reference-rounding' (the same algorithm in 80-bit
+    long double — oracle/liboracle_ld.so — sides with the engine on every differing row), 'precision-decided'
+    (the reference changes its OWN answer on every differing row when computed in long double: an ill-conditioned
+    arg-max), or 'UNEXPLAINED'.  The classification tests/dev/fuzz_parity.py prints, shared with the -m gpu
+    tests so that a regression cannot hide behind the near-tie flag."""
+    from nadavca_amd import synthetic
+    from oracle.oracle import LongDoubleReferee
+    ev2 = np.asarray(ev).reshape(-1, 2)
+    exp = np.asarray(exp).reshape(-1, 2)
+    if ev2.shape != exp.shape:
+        return 'UNEXPLAINED'
+    c = case
+    ext = np.concatenate([c['context_before'], c['reference'], c['context_after']]).astype(np.int64)
+    ids = synthetic.kmer_ids(ext, len(c['context_before']), len(c['reference']), k, central, alphabet)
+    mean = fb_model[3]
+    same_level = np.concatenate([[False], mean[ids[1:]] == mean[ids[:-1]]])  # base j vs j-1
+    rows = np.nonzero((ev2 != exp).any(axis=1))[0]
+
+    def flat(j):  # every boundary of row j that differs lies between equal levels
+        return (ev2[j, 0] == exp[j, 0] or same_level[j]) and \
+               (ev2[j, 1] == exp[j, 1] or (j + 1 < len(ids) and same_level[j + 1]))
+
+    if all(flat(j) for j in rows):
+        return 'flat-plateau'
+    ld = referee if referee is not None else LongDoubleReferee(*fb_model)
+    hp = ld.refine_alignment(c['signal'], c['reference'], c['context_before'], c['context_after'],
+                             c['approximate_alignment'], bw, mel, tr)
+    if hp.shape != exp.shape:
+        return 'UNEXPLAINED'
+    if all(np.array_equal(ev2[j], hp[j]) or flat(j) for j in rows):
+        return 'reference-rounding'
+    if all(not np.array_equal(exp[j], hp[j]) or flat(j) for j in rows):
+        return 'precision-decided'
+    return 'UNEXPLAINED'
