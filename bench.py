@@ -10,10 +10,11 @@ synthetic reads that is already resident in HBM.  Workloads (``--workload``):
                         Reads shard embarrassingly: every rank aligns its own batch (weak scaling, no
                         data-path collective).
   cfg3_snps             configs[2]: ``estimate_log_likelihoods`` (wobbling on) over the same shape.
-  cfg4_consensus        configs[3]: the ``estimate_snps(independent=False)`` data path per rank —
-                        log-likelihoods -> normalise / strand-flip / scatter-add into the per-position sums
-                        (device) -> ONE reduce(sum) of the packed [L, 5] f64 buffer over all ranks (RCCL over
-                        xGMI when N > 1) -> posterior on the root.  Reads per rank fixed (weak scaling).
+  cfg4_consensus        configs[3]: the ``estimate_snps(independent=False)`` data path, 200 000 reads over the ranks
+                        (strong scaling: 200 000 / N each) — pooled median / MAD over ALL ranks' samples (exact
+                        distributed selection, <= 32 tiny all-reduces) -> normalise -> log-likelihoods -> strand-flip /
+                        scatter-add into the per-position sums (device) -> ONE reduce(sum) of the packed [L, 5] f64
+                        buffer (RCCL over xGMI when N > 1) -> posterior on the root.
   cfg5_long             configs[4] shape on one GPU: ~50 000-sample reads, bandwidth 1000.
   api_align_signal      the public ``nadavca_amd.align_signal()`` call itself (host objects in, host arrays
                         out: normalisation, two alignments, two linear re-fits) over a ``ReadBatch``.
@@ -22,8 +23,9 @@ Rank 0 prints ONE JSON line with the contract keys plus
   "roofline":     the dominant kernel against the roofline that bounds it — align: HBM, algorithmic bytes
                   (B_align from the run's actual bands) / its HIP-event-timed duration (the
                   reverse-sweep and forward-sweep launches together); SNP kernels: FP64 vector issue
-  "e2e":          (cfg2_align, N=1) the same batch through the host-pointer entry point: H2D + plan + align
-                  + D2H, never `value`
+  "e2e":          (cfg2_align, N=1) host arrays in -> host arrays out: a stream of batches through
+                  nvk_refine_alignment_submit/_wait (PCIe copies behind the kernels), and "e2e_single_call" for one
+                  nvk_refine_alignment_batch call; never `value`
   "cpu_baseline": the CPU oracle (oracle/_ref = the reference compiled in place when present, else the C
                   restatement) timed on this box's host cores on a bounded sample of the same reads.
 """
@@ -169,6 +171,8 @@ def main():
     wl = dict(synthetic.WORKLOADS['cfg2_align' if wname.startswith('api_') else wname])
     n_reads = args.reads or wl.pop('n_reads')
     wl.pop('n_reads', None)
+    if wname == 'cfg4_consensus' and not args.reads:
+        n_reads = max(1, n_reads // world)   # BASELINE config 4: 200 000 reads sharded over the ranks
     ref_len = wl.pop('reference_length', 10000)
     bandwidth, mel = wl['bandwidth'], 2
     model = synthetic.synth_model_arrays(7, k=args.k, central=(args.k - 1) // 2) if args.k else synthetic.load_model_arrays()
@@ -205,7 +209,10 @@ def main():
         stats_of = lambda: ctx.last_batch_stats()
     else:
         # every rank gets its own reads (seed offset by rank): weak scaling over independent reads
-        batch = synthetic.make_batch(n_reads, model, seed=1000 + rank, **wl)
+        # (config 4: at most 10 000 simulated reads per rank, repeated to the rank's share — synthetic.tile_batch)
+        batch = synthetic.make_batch(min(n_reads, 10000), model, seed=1000 + rank, **wl)
+        if n_reads > batch.n:
+            batch = synthetic.tile_batch(batch, n_reads)
         dbatch = DeviceBatch(batch, device)
         events = torch.zeros((dbatch.total_ref, 2), dtype=torch.int32, device=device)
         ll = None if is_align else torch.zeros((dbatch.total_ref, 4), dtype=torch.float64, device=device)
@@ -233,6 +240,10 @@ def main():
             acc = torch.zeros((ref_len, 4), dtype=torch.float64, device=device)
             cov = torch.zeros(ref_len, dtype=torch.int64, device=device)
             extra['groups'] = len(groups)
+            # the reads as a sequencer hands them over (raw = 12 x + 90, make_read_spec's scale): every step starts
+            # with the pooled median / MAD over ALL ranks' samples (estimate_snps.py:61) — the path's first exchange
+            from nadavca_amd.device import select_hist_dev, normalize_apply_dev
+            d_raw = dbatch.signal * 12.0 + 90.0
 
         def step():
             if is_align:
@@ -240,6 +251,9 @@ def main():
             elif wname == 'cfg3_snps':
                 estimate_log_likelihoods_dev(dbatch, bandwidth, mel, km, True, ll, status)
             else:
+                cs = D.pooled_centre_scale(select_hist_dev(ctx, d_raw), d_raw.numel(), device=device)
+                normalize_apply_dev(ctx, d_raw, cs[0], cs[1], out=dbatch.signal)
+                extra['centre_scale'] = cs
                 estimate_log_likelihoods_dev(dbatch, bandwidth, mel, km, True, ll, status)
                 acc.zero_()
                 cov.zero_()
@@ -303,10 +317,15 @@ def main():
                         'reads_tie_near': stats['reads_tie_near']})
         if wname == 'cfg4_consensus':
             cfg.update({'reference_length': ref_len, 'chunk_groups': extra.get('groups'),
-                        'collective': 'none (1 rank)' if dist is None else 'reduce(sum) of [L,5] f64 over RCCL'})
+                        'reads_total': n_reads * world, 'unique_simulated_reads_per_rank': min(n_reads, 10000),
+                        'pooled_centre_scale': list(extra.get('centre_scale', ())),
+                        'collectives': 'none (1 rank)' if dist is None else
+                                       'pooled median/MAD: <= 32 all-reduces of 256 counts; consensus: ONE '
+                                       'reduce(sum) of [L,5] f64; both over RCCL'})
         out = {'metric': metric, 'value': total_reads / dt, 'unit': 'reads/s', 'n_gpus': world,
                'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1000.0 * dt / args.steps,
-               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
+               'higher_is_better': True, 'scaling': 'strong' if wname == 'cfg4_consensus' and not args.reads else 'weak',
+               'vs_baseline': None, 'dtype': 'f64',
                'data': 'synthetic', 'config': cfg}
         kname = 'align' if (is_align or wname == 'api_align_signal') else 'ell_hyp'
         ms, launches = timing[kname]
@@ -348,16 +367,48 @@ def main():
         elif is_api:
             out['kernels_ms_per_step'] = {k: v[0] / args.steps for k, v in timing.items() if v[1]}
         if wname == 'cfg2_align' and world == 1:
-            # T_e2e: host arrays in -> host arrays out through the host-pointer entry point
+            # T_e2e: host arrays in -> host arrays out, every PCIe copy inside the timed region.
+            # (a) a STREAM of batches through nvk_refine_alignment_submit / _wait, two in flight: the upload of
+            #     batch k+1 and the download of batch k-1 run behind the kernels of batch k (csrc/pipeline.hip);
+            # (b) ONE call of nvk_refine_alignment_batch: the batch in three growing chunks over three lanes —
+            #     what a single call can hide is bounded by its first upload and a half-empty chip at its start.
             flat = dtw.FlatBatch.from_arrays(batch.signal, batch.sig_off, batch.reference, batch.ref_off,
                                              batch.context_before, batch.cb_off, batch.context_after,
                                              batch.ca_off, batch.anchors, batch.anc_off)
+            ev_res = events.cpu().numpy()
+            rs = dtw.RefineStream(km, bandwidth, mel, True)
+            outs = [(np.zeros((dbatch.total_ref, 2), np.int32), np.zeros(n_reads, np.int32),
+                     np.zeros(n_reads, np.int32)) for _ in range(2)]
+            for i in range(6):   # warm-up: every lane once or twice (its staging, its 25 GB of spill), page-ins
+                rs.wait(rs.submit(flat, out=outs[i % 2]))
+            K = max(args.steps, 4)
+            t1 = time.perf_counter()
+            tickets = []
+            for i in range(K):
+                tickets.append(rs.submit(flat, out=outs[i % 2]))
+                if i >= 1:
+                    got = rs.wait(tickets[i - 1])
+            got = rs.wait(tickets[-1])
+            ts = time.perf_counter() - t1
+            same = bool(np.array_equal(got[0], ev_res))
+            algo = dbatch.algorithmic_bytes_align(stats['band_cells'])
+            out['e2e'] = {'reads_per_s': n_reads * K / ts, 'ms_per_batch': 1000.0 * ts / K, 'batches': K,
+                          'in_flight': 2, 'frac_of_value': (n_reads * K / ts) / out['value'],
+                          'equals_resident_result': same,
+                          'roofline': {'bound': 'hbm', 'achieved': algo / (ts / K) / 1e9, 'peak': HBM_PEAK_GBS,
+                                       'unit': 'GB/s', 'frac': algo / (ts / K) / 1e9 / HBM_PEAK_GBS,
+                                       'note': 'algorithmic bytes of the align kernel / whole-batch wall time, '
+                                               'PCIe-inclusive'},
+                          'includes': 'per batch: H2D of every input array (pageable host memory) + plan + align + '
+                                      'D2H of events, status and tie flags; nvk_refine_alignment_submit/_wait'}
             dtw.refine_alignment_flat(flat, bandwidth, mel, km, True)
             t1 = time.perf_counter()
-            dtw.refine_alignment_flat(flat, bandwidth, mel, km, True)
+            ev1, _ = dtw.refine_alignment_flat(flat, bandwidth, mel, km, True)
             te = time.perf_counter() - t1
-            out['e2e'] = {'reads_per_s': n_reads / te, 'ms': 1000.0 * te,
-                          'includes': 'H2D (pageable host arrays) + plan + align + D2H, nvk_refine_alignment_batch'}
+            out['e2e_single_call'] = {'reads_per_s': n_reads / te, 'ms': 1000.0 * te,
+                                      'equals_resident_result': bool(np.array_equal(ev1, ev_res)),
+                                      'includes': 'one nvk_refine_alignment_batch call: H2D + plan + align + D2H in '
+                                                  'three overlapped chunks'}
         if not args.no_cpu_baseline and world == 1 and batch is not None:  # reported at N=1 only (contract)
             out['cpu_baseline'] = cpu_baseline(batch, model, bandwidth, mel, wname)
             out['gpu_over_cpu'] = out['value'] / world / out['cpu_baseline']['value']

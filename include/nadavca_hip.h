@@ -20,7 +20,7 @@
  * context_before, context_after, approximate_alignment) concatenated over reads.
  *
  * Two flavours of each operator:
- *   nvk_xxx_batch      host pointers   (stages H2D, runs, copies results back)
+ *   nvk_xxx_batch      host pointers   (uploads, runs and downloads in overlapped chunks: csrc/pipeline.hip)
  *   nvk_xxx_batch_dev  device pointers (inputs already resident in HBM; runs on the
  *                      context's HIP stream; results are complete on return)
  *
@@ -120,11 +120,19 @@ int nvk_last_retry_count(nvk_ctx *ctx, int64_t *n_reads);
  * row (the same test file; rates per class in DESIGN.md 2.1).  Every difference ever observed sits in a read
  * with the ULP bit, on a boundary between two bases with the same k-mer level or where the reference's
  * answer changes when it is recomputed in 80-bit long double.
- *   nvk_last_tie_count    reads of the last nvk_refine_alignment_batch[_dev] call with any bit set
+ * Beside the three classes, nvk_last_tie_flags carries a structural mark,
+ *   NVK_TIE_PLATEAU  two ADJACENT bases of the read have the same k-mer level (a homopolymer run of k+1 bases, or
+ *                  a model with few levels): the boundary between their events is mathematically unidentifiable —
+ *                  the posterior is exactly flat over a stretch of samples — and the reference places it by the
+ *                  rounding noise of its log-doubles.  All but 24 of the 3 400 differing reads the randomised runs
+ *                  ever produced differ only at such boundaries.  Not a tie class: it is known
+ *                  from the sequence alone, is not counted by nvk_last_tie_count(s), and says nothing about the
+ *                  rest of the read.
+ *   nvk_last_tie_count    reads of the last nvk_refine_alignment_batch[_dev] call with a class bit set
  *   nvk_last_tie_counts   the same per class (a read may carry several bits)
  *   nvk_last_tie_flags    per read, the OR of its classes; out_flags i32[n_reads] (host), n_reads must be that
  *                         call's n_reads */
-enum { NVK_TIE_EXACT = 1, NVK_TIE_NEAR = 2, NVK_TIE_ULP = 4 };
+enum { NVK_TIE_EXACT = 1, NVK_TIE_NEAR = 2, NVK_TIE_ULP = 4, NVK_TIE_PLATEAU = 8 };
 int nvk_last_tie_count(nvk_ctx *ctx, int64_t *n_reads);
 int nvk_last_tie_counts(nvk_ctx *ctx, int64_t *n_exact, int64_t *n_near, int64_t *n_ulp);
 int nvk_last_tie_flags(nvk_ctx *ctx, int64_t n_reads, int32_t *out_flags);
@@ -175,6 +183,26 @@ int nvk_refine_alignment_batch_dev(nvk_model *model, int64_t n_reads, int64_t to
                                    const int64_t *anc_off, int bandwidth, int min_event_length,
                                    int model_transitions, int32_t *out_events,
                                    int32_t *out_status);
+
+/* The same operator for a STREAM of batches (T_e2e of SURVEY.md 8d: host arrays in, host arrays out, the PCIe
+ * copies hidden behind the kernels).  The reference pays its copy-in / copy-out around every call
+ * (dtwmodule.cpp:19-28); here nvk_refine_alignment_submit uploads batch k+1 and returns at once with a ticket
+ * while the kernels of batch k still run (a few lanes: private streams, workspaces and worker threads, made on
+ * first use, csrc/pipeline.hip), and nvk_refine_alignment_wait(ticket) returns when that batch's events and
+ * status are in the arrays given at submit.  All host arrays of a batch must stay valid and untouched from
+ * submit until its wait returns (a later submit may deliver an earlier batch's results; its verdict is kept
+ * for its wait).  out_tie_flags: i32[n_reads] for the per-read NVK_TIE_* bits, or NULL.  Tickets are per
+ * context; wait for every ticket exactly once.  nvk_refine_alignment_batch itself runs its one batch through
+ * the same lanes in growing chunks. */
+int nvk_refine_alignment_submit(nvk_model *model, int64_t n_reads, const double *signal,
+                                const int64_t *sig_off, const int32_t *reference,
+                                const int64_t *ref_off, const int32_t *ctx_before,
+                                const int64_t *cb_off, const int32_t *ctx_after,
+                                const int64_t *ca_off, const int32_t *anchors,
+                                const int64_t *anc_off, int bandwidth, int min_event_length,
+                                int model_transitions, int32_t *out_events, int32_t *out_status,
+                                int32_t *out_tie_flags, int64_t *ticket);
+int nvk_refine_alignment_wait(nvk_model *model, int64_t ticket);
 
 /* replaces dtw.estimate_log_likelihoods(signal, reference, context_before, context_after,
  * approximate_alignment, bandwidth, min_event_length, kmer_model, model_wobbling)
@@ -246,6 +274,19 @@ int nvk_posterior(nvk_ctx *ctx, int64_t len, int64_t n_segments, const int64_t *
  * centre_scale f64[2*n_groups] receives (centre, scale) per group, or NULL.  Device pointers. */
 int nvk_normalize_groups_dev(nvk_ctx *ctx, int64_t n_groups, const double *raw, const int64_t *grp_off,
                              double *out, double *centre_scale);
+
+/* The same normalisation when the samples of the one group are SHARDED over several GPUs (estimate_snps takes
+ * ONE median / MAD over all reads, estimate_snps.py:61, read.py:68-81; SURVEY.md 8e "caveat"): the exact
+ * selection is a radix select over the order-preserving 64-bit key of a double, 8 passes of 8 bits, and only the
+ * 256 counts of a pass have to cross ranks.  nvk_select_hist_dev counts, among this rank's x[0..n), the values
+ * f(x) whose key agrees with `key_prefix` in the bits above pass `pass` (0 = most significant byte), by the byte
+ * of that pass: hist256 u64[256] (device, overwritten).  mode 0: f(x) = x; mode 1: f(x) = |x - centre|.  The
+ * caller sums the counts over the ranks (an all-reduce of 2 KB), picks the bucket holding the wanted rank and
+ * extends the prefix (nadavca_amd/distributed.py: pooled_median).  nvk_normalize_apply_dev then writes
+ * clip((x - centre) / scale, -5, 5); out may alias x.  Device pointers. */
+int nvk_select_hist_dev(nvk_ctx *ctx, const double *x, int64_t n, int mode, double centre, uint64_t key_prefix,
+                        int pass, uint64_t *hist256);
+int nvk_normalize_apply_dev(nvk_ctx *ctx, const double *x, int64_t n, double centre, double scale, double *out);
 
 /* replaces the per-event numpy.mean of align_signal.py:66-69 and read.py:85-86: for every base g of
  * every read, the mean of signal[sig_off[read] + events[2g] .. + events[2g+1]) with `events` as written

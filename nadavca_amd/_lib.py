@@ -25,6 +25,7 @@ READ_TOO_WIDE = -3
 
 TIE_EXACT = 1   # nvk_last_tie_flags: some path comparison of the read met two exactly equal scores
 TIE_NEAR = 2    # ... two scores closer than 2^-24 relative (beyond the class below)
+TIE_PLATEAU = 8  # structural mark: two adjacent bases with the same k-mer level (boundary unidentifiable)
 TIE_ULP = 4     # ... two scores within 64 ulps of the reference's log value, not equal (where its rounding may decide)
 
 K_PLAN, K_ALIGN, K_ELL_SWEEP, K_ELL_HYP, K_EXPECTED, K_CONSENSUS, K_POSTERIOR, K_RENORM = range(8)
@@ -59,6 +60,8 @@ SIGNATURES = {
     'nvk_expected_signal_batch': (_int, [_vp, _i64] + [_vp] * 7),
     'nvk_expected_signal_batch_dev': (_int, [_vp, _i64, _i64] + [_vp] * 7),
     'nvk_refine_alignment_batch': (_int, [_vp, _i64] + [_vp] * 10 + [_int, _int, _int, _vp, _vp]),
+    'nvk_refine_alignment_submit': (_int, [_vp, _i64] + [_vp] * 10 + [_int, _int, _int, _vp, _vp, _vp, C.POINTER(_i64)]),
+    'nvk_refine_alignment_wait': (_int, [_vp, _i64]),
     'nvk_refine_alignment_batch_dev': (_int, [_vp, _i64, _i64, _i64, _i64] + [_vp] * 10 + [_int, _int, _int, _vp, _vp]),
     'nvk_estimate_log_likelihoods_batch': (_int, [_vp, _i64] + [_vp] * 10 + [_int, _int, _int, _vp, _vp]),
     'nvk_estimate_log_likelihoods_batch_dev': (_int, [_vp, _i64, _i64, _i64, _i64] + [_vp] * 10 + [_int, _int, _int, _vp, _vp]),
@@ -68,6 +71,8 @@ SIGNATURES = {
     'nvk_posterior_segments_dev': (_int, [_vp, _i64, _i64, _vp, _int, _int, _dbl, _vp, _vp, _vp]),
     'nvk_posterior': (_int, [_vp, _i64, _i64, _vp, _int, _int, _dbl, _vp, _vp, _vp]),
     'nvk_normalize_groups_dev': (_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
+    'nvk_select_hist_dev': (_int, [_vp, _vp, _i64, _int, _dbl, C.c_uint64, _int, _vp]),
+    'nvk_normalize_apply_dev': (_int, [_vp, _vp, _i64, _dbl, _dbl, _vp]),
     'nvk_event_means_dev': (_int, [_vp, _i64, _i64] + [_vp] * 6),
     'nvk_linfit_rescale_dev': (_int, [_vp, _i64] + [_vp] * 7),
     'nvk_splev_groups_dev': (_int, [_vp, _i64] + [_vp] * 5 + [_int, _vp]),

@@ -128,9 +128,8 @@ def align_signal_batch(reference_filename, read_batch, config=defaults.CONFIG_FI
     dbatch = DeviceBatch.from_windows(norm, sa, device)
     events, status, fits = refine_renorm_loop_dev(dbatch, config['bandwidth'], config['min_event_length'],
                                                   kmer_model, config['model_transitions'], renorm_rounds)
-    if bool((status < 0).any()):
-        bad = torch.nonzero(status < 0).reshape(-1)[:8]
-        raise ValueError('refine_alignment: invalid input for read(s) %s' % sa.live[bad].tolist())
+    from .estimate_snps import _check_status
+    _check_status('refine_alignment', status, sa.live)   # (too-wide reads stay in `status`, like reads without a path)
     # the same linear maps for the samples outside the windows (the reference rescales the whole read,
     # align_signal.py:73): per read (x - intercept) / slope, fit after fit, on the device
     total = int(rb.sig_off[-1])

@@ -12,7 +12,16 @@ namespace dens {
 // exact 0.  2^(y/128) = 2^(k) * 2^(j/128) * 2^(g/128), j from a 128-entry LDS table, the last factor
 // a degree-5 Taylor polynomial (|g| <= 1/2: truncation 5e-19, i.e. below rounding level).  A non-finite
 // sample gives NaN, which the caller's range check turns into a retry by the exact kernel.
-constexpr int ETN = 128;  // table entries: 2^(j/128)
+#ifndef NVK_ETN_LOG2
+#define NVK_ETN_LOG2 7
+#endif
+constexpr int ETL = NVK_ETN_LOG2;  // log2 of the table size
+constexpr int ETN = 1 << ETL;      // table entries: 2^(j/ETN).  128 (degree-5 polynomial) or 32 (degree 6: a 32-entry
+                                   // table of doubles is exactly one 256-byte bank row, so a gather from it cannot
+                                   // conflict — same address, same bank, broadcast; the 128-entry table puts four
+                                   // entries on every bank and the random gather takes 19-24 % of the LDS cycles as
+                                   // conflicts, profiles/r02i_pmc_summary.txt)
+static_assert(ETL == 7 || ETL == 5, "polynomial coefficients exist for 128 and 32 entries");
 // v_fma_f64 with three VGPR operands: keeps the compiler from choosing v_fmac + a 64-bit register
 // copy of the coefficient per term
 __device__ __forceinline__ double fma_vvv(double a, double b, double c) {
@@ -20,7 +29,23 @@ __device__ __forceinline__ double fma_vvv(double a, double b, double c) {
   asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
   return r;
 }
-#define DENS_SCALE (128.0 * 0x1.71547652b82fep+0)
+#define DENS_SCALE ((double)(1 << NVK_ETN_LOG2) * 0x1.71547652b82fep+0)
+// 2^(g/ETN), |g| <= 1/2: Taylor polynomial in g (truncation below 2^-57 relative for both table sizes)
+__device__ __forceinline__ double dens_poly(double gq) {
+#if NVK_ETN_LOG2 == 7
+  double p = fma_vvv(gq, 0x1.5d87fe78a6731p-45, 0x1.3b2ab6fba4e77p-35);
+  p = fma_vvv(p, gq, 0x1.c6b08d704a0c0p-26);
+  p = fma_vvv(p, gq, 0x1.ebfbdff82c58fp-17);
+  p = fma_vvv(p, gq, 0x1.62e42fefa39efp-8);
+#else
+  double p = fma_vvv(gq, 0x1.430912f86c787p-43, 0x1.5d87fe78a6731p-35);
+  p = fma_vvv(p, gq, 0x1.3b2ab6fba4e77p-27);
+  p = fma_vvv(p, gq, 0x1.c6b08d704a0c0p-20);
+  p = fma_vvv(p, gq, 0x1.ebfbdff82c58fp-13);
+  p = fma_vvv(p, gq, 0x1.62e42fefa39efp-6);
+#endif
+  return fma(p, gq, 1.0);
+}
 __device__ __forceinline__ double density(double x, double mean, double ac, double mc, int dshift,
                                           const double *etab) {
   const double d = x - mean;
@@ -29,12 +54,8 @@ __device__ __forceinline__ double density(double x, double mean, double ac, doub
   const double gq = y - kk;
   const int ki = (int)kk;
   const double tj = etab[ki & (ETN - 1)];
-  double p = fma_vvv(gq, 0x1.5d87fe78a6731p-45, 0x1.3b2ab6fba4e77p-35);
-  p = fma_vvv(p, gq, 0x1.c6b08d704a0c0p-26);
-  p = fma_vvv(p, gq, 0x1.ebfbdff82c58fp-17);
-  p = fma_vvv(p, gq, 0x1.62e42fefa39efp-8);
-  p = fma(p, gq, 1.0);
-  return ldexp(tj * p, (ki >> 7) + dshift);
+  const double p = dens_poly(gq);
+  return ldexp(tj * p, (ki >> ETL) + dshift);
 }
 
 // The same in two halves, so that the sample and table reads of the NEXT step's density can be issued
@@ -56,15 +77,11 @@ __device__ __forceinline__ DensHalf density_begin(double x, double mean, double 
 #else
   h.tj = etab[h.ki & (ETN - 1)];
 #endif
-  double p = fma_vvv(gq, 0x1.5d87fe78a6731p-45, 0x1.3b2ab6fba4e77p-35);
-  p = fma_vvv(p, gq, 0x1.c6b08d704a0c0p-26);
-  p = fma_vvv(p, gq, 0x1.ebfbdff82c58fp-17);
-  p = fma_vvv(p, gq, 0x1.62e42fefa39efp-8);
-  h.p = fma(p, gq, 1.0);
+  h.p = dens_poly(gq);
   return h;
 }
 __device__ __forceinline__ double density_end(const DensHalf &h, int dshift) {
-  return ldexp(h.tj * h.p, (h.ki >> 7) + dshift);
+  return ldexp(h.tj * h.p, (h.ki >> ETL) + dshift);
 }
 
 
@@ -83,12 +100,8 @@ __device__ __forceinline__ double constant_density(double ac) {
   const double gq = y - kk;
   const int ki = (int)kk;
   const double tj = table_entry(ki & (ETN - 1));
-  double p = fma_vvv(gq, 0x1.5d87fe78a6731p-45, 0x1.3b2ab6fba4e77p-35);
-  p = fma_vvv(p, gq, 0x1.c6b08d704a0c0p-26);
-  p = fma_vvv(p, gq, 0x1.ebfbdff82c58fp-17);
-  p = fma_vvv(p, gq, 0x1.62e42fefa39efp-8);
-  p = fma(p, gq, 1.0);
-  return ldexp(tj * p, ki >> 7);
+  const double p = dens_poly(gq);
+  return ldexp(tj * p, ki >> ETL);
 }
 
 // row constants as density() wants them: the reference's ac/mc (kmer_model.cpp:9-12) times

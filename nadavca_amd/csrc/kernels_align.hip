@@ -423,8 +423,9 @@ __global__ __launch_bounds__(64) void align_kernel(AlignArgs g) {
     }
     {
       const bool ax = __any(amb_x), an = __any(amb_n), au = __any(amb_u);
-      if ((ax || an || au) && lane == 0)
-        g.ties[rd] = (ax ? NVK_TIE_EXACT : 0) | (an ? NVK_TIE_NEAR : 0) | (au ? NVK_TIE_ULP : 0);
+      if ((ax || an || au || m.rsv) && lane == 0)
+        g.ties[rd] = (ax ? NVK_TIE_EXACT : 0) | (an ? NVK_TIE_NEAR : 0) | (au ? NVK_TIE_ULP : 0) |
+                     (m.rsv ? NVK_TIE_PLATEAU : 0);
     }
     if (lane == 0) {
       int32_t *ev = g.out_events + 2 * m.ref_off;

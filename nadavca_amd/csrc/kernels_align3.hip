@@ -1160,8 +1160,9 @@ __global__ __launch_bounds__(64 * W, PHASE == 1 ? (W > 1 ? NVK_LB_REV_TEAM : NVK
       if (gl == 0) g.out_status[rd] = NVK_READ_NO_PATH;
       continue;
     }
-    if (gl == 0 && (amb_x | amb_n | amb_u) != 0)
-      g.ties[rd] = (amb_x != 0 ? NVK_TIE_EXACT : 0) | (amb_n != 0 ? NVK_TIE_NEAR : 0) | (amb_u != 0 ? NVK_TIE_ULP : 0);
+    if (gl == 0 && ((amb_x | amb_n | amb_u) != 0 || m.rsv))
+      g.ties[rd] = (amb_x != 0 ? NVK_TIE_EXACT : 0) | (amb_n != 0 ? NVK_TIE_NEAR : 0) | (amb_u != 0 ? NVK_TIE_ULP : 0) |
+                   (m.rsv ? NVK_TIE_PLATEAU : 0);
     if (gl == 0) {
       int32_t *ev = g.out_events + 2 * m.ref_off;
       int st = NVK_READ_OK;

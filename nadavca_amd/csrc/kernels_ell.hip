@@ -107,7 +107,7 @@ __device__ __forceinline__ X add_lazy(X a, X b) {
 // e(x) as (mantissa in [1,2), exponent): dens::density without its final ldexp
 __device__ __forceinline__ X density_x(double x, double mean, double ac, double mc, const double *etab) {
   const dens::DensHalf h = dens::density_begin(x, mean, ac, mc, etab);
-  return X{h.tj * h.p, h.ki >> 7};
+  return X{h.tj * h.p, h.ki >> dens::ETL};
 }
 
 // fused_step with lazy sums; gb/ga are the two mixture components at this cell's sample

@@ -215,6 +215,7 @@ __global__ __launch_bounds__(PLAN_T) void plan_kernel(DeviceModel dm, BatchArgs 
   // --- row table -----------------------------------------------------------------------------
   RowParam *rp = rows + m.row_off;
   int badband = 0;
+  int plateau = 0;  // two adjacent bases with the same k-mer level (NVK_TIE_PLATEAU)
   long long cells = 0;
   for (int r = tid; r < T; r += PLAN_T) {
     RowParam p;
@@ -238,6 +239,7 @@ __global__ __launch_bounds__(PLAN_T) void plan_kernel(DeviceModel dm, BatchArgs 
         double m2 = dm.mean[kmer_id(dm, ref, R, cb, nb, ca, na, i + 1)];
         p.ac = (m1 == m2) ? -INFINITY : log_p_in;
         p.mel = 0;
+        plateau |= (m1 == m2) ? 1 : 0;
       } else {
         int i = (mode == PLAN_ALIGN_TRANS) ? r / 2 : r;
         int64_t id = kmer_id(dm, ref, R, cb, nb, ca, na, i);
@@ -250,6 +252,9 @@ __global__ __launch_bounds__(PLAN_T) void plan_kernel(DeviceModel dm, BatchArgs 
     rp[r] = p;
   }
   badband = __syncthreads_or(badband);
+  if (mode != PLAN_ALIGN_TRANS)  // (without transition rows: steps r and r + 1 are consecutive bases)
+    for (int r = tid; r + 2 < T; r += PLAN_T) plateau |= (rp[r].mean == rp[r + 1].mean) ? 1 : 0;
+  plateau = __syncthreads_or(plateau);
   cells = wave_sum(cells);
   if (lane == 0) atomicAdd(&sh_cells, (unsigned long long)cells);
   __syncthreads();
@@ -427,6 +432,7 @@ __global__ __launch_bounds__(PLAN_T) void plan_kernel(DeviceModel dm, BatchArgs 
     // 16 and flushes its bit words every 32 steps, and with a whole number of each its loops need no end tests
     m.pad = (m.pad + 31) & ~31;
     m.cells = cells;
+    m.rsv = plateau ? 1 : 0;
     if (badband) m.status = NVK_READ_BAD_BAND;
     metas[rd] = m;
     if (!badband) {
@@ -656,7 +662,7 @@ __global__ void count_flags_kernel(const int32_t *flags, int64_t n, int32_t *out
   int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int f = (g < n) ? flags[g] : 0;
   // (three counts of at most 2^20 each would fit one word; kept apart for n up to 2^31)
-  int v = (f != 0) ? 1 : 0, v0 = f & 1, v1 = (f >> 1) & 1, v2 = (f >> 2) & 1;
+  int v = ((f & 7) != 0) ? 1 : 0, v0 = f & 1, v1 = (f >> 1) & 1, v2 = (f >> 2) & 1;  // (bit 3, the plateau mark, is not a tie class)
   for (int d = 32; d >= 1; d >>= 1) {
     v += __shfl_xor(v, d, 64);
     v0 += __shfl_xor(v0, d, 64);

@@ -180,6 +180,39 @@ __global__ __launch_bounds__(NT) void big_clip_kernel(const double *x, int64_t n
   }
 }
 
+// ---- the same selection with the samples sharded over several GPUs (estimate_snps normalises ALL reads with one
+// median / MAD, estimate_snps.py:61): every rank counts its own samples, the 256 counts of a pass are summed over
+// the ranks by the caller (one tiny all-reduce per pass, nadavca_amd/distributed.py) and every rank picks the same
+// bucket.  Stateless: the key prefix found so far and the centre come in as arguments.
+template <int MODE>
+__global__ __launch_bounds__(NT) void shard_hist_kernel(const double *x, int64_t n, int pass,
+                                                       unsigned long long prefix, double centre,
+                                                       unsigned long long *out) {
+  __shared__ unsigned int hist[256];
+  for (int q = threadIdx.x; q < 256; q += NT) hist[q] = 0u;
+  __syncthreads();
+  const int shift = 56 - 8 * pass;
+  const unsigned long long mask = pass ? (~0ull << (shift + 8)) : 0ull;
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+    const double v = MODE ? fabs(x[i] - centre) : x[i];
+    const unsigned long long k = key_of(v);
+    if ((k & mask) == prefix) atomicAdd(&hist[(unsigned)(k >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  for (int q = threadIdx.x; q < 256; q += NT)
+    if (hist[q]) atomicAdd(&out[q], (unsigned long long)hist[q]);
+}
+
+__global__ __launch_bounds__(NT) void shard_clip_kernel(const double *x, int64_t n, double centre, double scale,
+                                                       double *out) {
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+    double v = (x[i] - centre) / scale;
+    v = (v < -5.0) ? -5.0 : v;
+    v = (v > 5.0) ? 5.0 : v;
+    out[i] = v;
+  }
+}
+
 // ---- numpy's pairwise summation (numpy/_core/src/umath/loops_utils.h.src, @TYPE@_pairwise_sum) ------
 __device__ double np_block_sum(const double *a, int64_t n) {  // n <= 128
   if (n < 8) {
@@ -446,6 +479,49 @@ extern "C" int nvk_normalize_groups_dev(nvk_ctx *ctx, int64_t n_groups, const do
                        grp_off, out, centre_scale);
   }
   NVK_HIP(hipGetLastError());
+  NVK_HIP(hipStreamSynchronize(ctx->stream));
+  return NVK_OK;
+}
+
+extern "C" int nvk_select_hist_dev(nvk_ctx *ctx, const double *x, int64_t n, int mode, double centre,
+                                   uint64_t key_prefix, int pass, uint64_t *hist256) {
+  if (!ctx || n < 0 || (n > 0 && !x) || !hist256 || pass < 0 || pass > 7 || (mode != 0 && mode != 1)) {
+    nvk_set_error("nvk_select_hist_dev: invalid argument");
+    return NVK_ERR_INVALID;
+  }
+  NVK_HIP(hipSetDevice(ctx->device));
+  NVK_HIP(hipMemsetAsync(hist256, 0, 256 * sizeof(uint64_t), ctx->stream));
+  if (n > 0) {
+    TimerScope ts(ctx, NVK_K_RENORM);
+    int64_t want = (n + NT - 1) / NT;
+    const unsigned blocks = (unsigned)(want < (int64_t)ctx->num_cus * 8 ? want : (int64_t)ctx->num_cus * 8);
+    if (mode == 0)
+      hipLaunchKernelGGL(shard_hist_kernel<0>, dim3(blocks), dim3(NT), 0, ctx->stream, x, n, pass,
+                         (unsigned long long)key_prefix, centre, (unsigned long long *)hist256);
+    else
+      hipLaunchKernelGGL(shard_hist_kernel<1>, dim3(blocks), dim3(NT), 0, ctx->stream, x, n, pass,
+                         (unsigned long long)key_prefix, centre, (unsigned long long *)hist256);
+    NVK_HIP(hipGetLastError());
+  }
+  NVK_HIP(hipStreamSynchronize(ctx->stream));
+  return NVK_OK;
+}
+
+extern "C" int nvk_normalize_apply_dev(nvk_ctx *ctx, const double *x, int64_t n, double centre, double scale,
+                                       double *out) {
+  if (!ctx || n < 0 || (n > 0 && (!x || !out))) {
+    nvk_set_error("nvk_normalize_apply_dev: invalid argument");
+    return NVK_ERR_INVALID;
+  }
+  if (n == 0) return NVK_OK;
+  NVK_HIP(hipSetDevice(ctx->device));
+  {
+    TimerScope ts(ctx, NVK_K_RENORM);
+    int64_t want = (n + NT - 1) / NT;
+    const unsigned blocks = (unsigned)(want < (int64_t)ctx->num_cus * 8 ? want : (int64_t)ctx->num_cus * 8);
+    hipLaunchKernelGGL(shard_clip_kernel, dim3(blocks), dim3(NT), 0, ctx->stream, x, n, centre, scale, out);
+    NVK_HIP(hipGetLastError());
+  }
   NVK_HIP(hipStreamSynchronize(ctx->stream));
   return NVK_OK;
 }

@@ -50,7 +50,7 @@ struct ReadMeta {
   int64_t cells;     // sum of band widths (algorithmic cell count)
   int32_t cw;        // align planner: 0, or the skew of a read served by a TEAM of ALIGN3_TEAM_W waves
                      // (kernels_align3.hip: one row per lane of 64 * ALIGN3_TEAM_W lanes; RowParam::off = cw * r)
-  int32_t rsv;
+  int32_t rsv;       // align planner: 1 if two adjacent bases of the read have the same k-mer level (NVK_TIE_PLATEAU)
 };
 
 // totals reduced over a batch by the planner (read back once by the host)

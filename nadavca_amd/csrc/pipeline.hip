@@ -83,15 +83,31 @@ struct Lane {
   bool quit = false;
   Job job;
   bool busy = false;  // a job is posted and not yet collected
+  int64_t ticket = -1;  // of that job when it came through nvk_refine_alignment_submit
   hipEvent_t uploaded = nullptr;
-  DevGrow signal, sig_off, ref, ref_off, cb, cb_off, ca, ca_off, anc, anc_off, out_a, out_st;
-  std::vector<int64_t> off[5];
+  // Device staging: the signal on its own (the bulk: one pageable copy), everything else — the five offset
+  // arrays rebased to the chunk, reference, contexts, anchors — packed into ONE pinned host buffer and sent with
+  // one asynchronous copy (ten small pageable copies cost ~0.4 ms of fixed overhead per chunk)
+  DevGrow signal, pack, out_a, out_st;
+  void *hpack = nullptr;   // pinned host image of `pack`
+  size_t hpack_cap = 0;
+  size_t at[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // byte offsets inside the pack: sig_off, ref_off, cb_off, ca_off, anc_off, ref, cb, ca, anc
   int alphabet = 4;
 };
 
 }  // namespace
 
+namespace {
+struct Verdict {
+  int64_t ticket;
+  int rc;
+  char err[256];
+};
+}  // namespace
+
 struct nvk_pipe_state {
+  std::vector<Verdict> verdicts;  // collected batches of nvk_refine_alignment_submit nobody has waited for yet
+  int64_t next_ticket = 0;
   int device = 0;
   int n_lanes = 0;
   Lane *lanes = nullptr;
@@ -112,11 +128,12 @@ void lane_run(Lane *L, Job *j) {
       break;
     }
     const double *d_sig = (const double *)L->signal.p;
-    const int64_t *d_so = (const int64_t *)L->sig_off.p, *d_ro = (const int64_t *)L->ref_off.p;
-    const int64_t *d_bo = (const int64_t *)L->cb_off.p, *d_ao = (const int64_t *)L->ca_off.p;
-    const int64_t *d_no = (const int64_t *)L->anc_off.p;
-    const int32_t *d_ref = (const int32_t *)L->ref.p, *d_cb = (const int32_t *)L->cb.p;
-    const int32_t *d_ca = (const int32_t *)L->ca.p, *d_anc = (const int32_t *)L->anc.p;
+    const char *pk = (const char *)L->pack.p;
+    const int64_t *d_so = (const int64_t *)(pk + L->at[0]), *d_ro = (const int64_t *)(pk + L->at[1]);
+    const int64_t *d_bo = (const int64_t *)(pk + L->at[2]), *d_ao = (const int64_t *)(pk + L->at[3]);
+    const int64_t *d_no = (const int64_t *)(pk + L->at[4]);
+    const int32_t *d_ref = (const int32_t *)(pk + L->at[5]), *d_cb = (const int32_t *)(pk + L->at[6]);
+    const int32_t *d_ca = (const int32_t *)(pk + L->at[7]), *d_anc = (const int32_t *)(pk + L->at[8]);
     if (j->kind == JOB_REFINE) {
       const size_t evb = (size_t)j->total_ref * 2 * 4;
       if (hipMemsetAsync(L->out_a.p, 0, evb ? evb : 16, c->stream) != hipSuccess) {
@@ -189,9 +206,9 @@ void pipe_destroy(nvk_pipe_state *p) {
       L.cv.notify_all();
       L.th.join();
     }
-    DevGrow *bufs[] = {&L.signal, &L.sig_off, &L.ref, &L.ref_off, &L.cb, &L.cb_off,
-                       &L.ca,     &L.ca_off,  &L.anc, &L.anc_off, &L.out_a, &L.out_st};
+    DevGrow *bufs[] = {&L.signal, &L.pack, &L.out_a, &L.out_st};
     for (DevGrow *b : bufs) b->release();
+    if (L.hpack) (void)hipHostFree(L.hpack);
     if (L.uploaded) (void)hipEventDestroy(L.uploaded);
     if (L.ctx) nvk_ctx_destroy(L.ctx);
   }
@@ -309,33 +326,46 @@ int lane_submit(nvk_pipe_state *p, Lane &L, const nvk_model *model, const HostBa
                 int32_t *out_status, int32_t *out_ties) {
   const int64_t n = b - a;
   const int64_t *src[5] = {h.sig_off, h.ref_off, h.cb_off, h.ca_off, h.anc_off};
-  for (int q = 0; q < 5; q++) {
-    try {
-      L.off[q].resize((size_t)n + 1);
-    } catch (const std::bad_alloc &) {
-      nvk_set_error("out of host memory");
-      return NVK_ERR_NOMEM;
-    }
-    const int64_t base = src[q][a];
-    for (int64_t i = 0; i <= n; i++) L.off[q][(size_t)i] = src[q][a + i] - base;
-  }
-  const int64_t ts = L.off[0][(size_t)n], tr = L.off[1][(size_t)n], tb = L.off[2][(size_t)n];
-  const int64_t ta = L.off[3][(size_t)n], tn = L.off[4][(size_t)n];
+  const int64_t ts = h.sig_off[b] - h.sig_off[a], tr = h.ref_off[b] - h.ref_off[a], tb = h.cb_off[b] - h.cb_off[a];
+  const int64_t ta = h.ca_off[b] - h.ca_off[a], tn = h.anc_off[b] - h.anc_off[a];
   L.model = *model;
   L.model.ctx = L.ctx;
   L.alphabet = model->dm.alphabet;
   const size_t no = (size_t)(n + 1) * 8;
-  int rc;
-  struct Up { DevGrow *d; const void *src; size_t bytes; };
-  const Up ups[10] = {{&L.ref, h.ref + h.ref_off[a], (size_t)tr * 4},   {&L.ref_off, L.off[1].data(), no},
-                      {&L.cb, h.cb + h.cb_off[a], (size_t)tb * 4},      {&L.cb_off, L.off[2].data(), no},
-                      {&L.ca, h.ca + h.ca_off[a], (size_t)ta * 4},      {&L.ca_off, L.off[3].data(), no},
-                      {&L.anc, h.anc + 2 * h.anc_off[a], (size_t)tn * 8}, {&L.anc_off, L.off[4].data(), no},
-                      {&L.sig_off, L.off[0].data(), no},                {&L.signal, h.signal + h.sig_off[a], (size_t)ts * 8}};
-  for (const Up &u : ups) {
-    if ((rc = u.d->reserve(u.bytes ? u.bytes : 16))) return rc;
-    if (u.bytes) NVK_HIP(hipMemcpyAsync(u.d->p, u.src, u.bytes, hipMemcpyHostToDevice, p->copy_in));
+  const size_t sizes[9] = {no, no, no, no, no, (size_t)tr * 4, (size_t)tb * 4, (size_t)ta * 4, (size_t)tn * 8};
+  size_t total = 0;
+  for (int q = 0; q < 9; q++) {
+    L.at[q] = total;
+    total += (sizes[q] + 63) & ~(size_t)63;  // (a 64-byte granule keeps every array 16-byte aligned; empty arrays too)
+    if (sizes[q] == 0) total += 64;
   }
+  int rc;
+  if (total > L.hpack_cap) {
+    if (L.hpack) (void)hipHostFree(L.hpack);
+    L.hpack = nullptr;
+    L.hpack_cap = 0;
+    const size_t want = total + total / 4 + 4096;
+    if (hipHostMalloc(&L.hpack, want, hipHostMallocDefault) != hipSuccess) {
+      L.hpack = nullptr;
+      nvk_set_error("hipHostMalloc of %zu bytes failed", want);
+      return NVK_ERR_NOMEM;
+    }
+    L.hpack_cap = want;
+  }
+  char *hp = (char *)L.hpack;
+  for (int q = 0; q < 5; q++) {  // offsets rebased to the chunk
+    int64_t *dst = (int64_t *)(hp + L.at[q]);
+    const int64_t base = src[q][a];
+    for (int64_t i = 0; i <= n; i++) dst[i] = src[q][a + i] - base;
+  }
+  if (tr) memcpy(hp + L.at[5], h.ref + h.ref_off[a], (size_t)tr * 4);
+  if (tb) memcpy(hp + L.at[6], h.cb + h.cb_off[a], (size_t)tb * 4);
+  if (ta) memcpy(hp + L.at[7], h.ca + h.ca_off[a], (size_t)ta * 4);
+  if (tn) memcpy(hp + L.at[8], h.anc + 2 * h.anc_off[a], (size_t)tn * 8);
+  if ((rc = L.pack.reserve(total))) return rc;
+  NVK_HIP(hipMemcpyAsync(L.pack.p, L.hpack, total, hipMemcpyHostToDevice, p->copy_in));
+  if ((rc = L.signal.reserve(ts ? (size_t)ts * 8 : 16))) return rc;
+  if (ts) NVK_HIP(hipMemcpyAsync(L.signal.p, h.signal + h.sig_off[a], (size_t)ts * 8, hipMemcpyHostToDevice, p->copy_in));
   const size_t outb = (kind == JOB_REFINE) ? (size_t)tr * 2 * 4 : (size_t)tr * L.alphabet * 8;
   if ((rc = L.out_a.reserve(outb ? outb : 16))) return rc;
   if ((rc = L.out_st.reserve((size_t)n * 4 + 16))) return rc;
@@ -380,8 +410,8 @@ int check_offsets(const char *what, const int64_t *off, int64_t n) {
   return NVK_OK;
 }
 
-int run_pipelined(nvk_model *model, int kind, int64_t n_reads, const HostBatch &h, int bandwidth, int mel,
-                  int flag, int32_t *out_events, double *out_ll, int32_t *out_status) {
+int validate(nvk_model *model, int kind, int64_t n_reads, const HostBatch &h, int bandwidth, int mel,
+             const void *out_main, const int32_t *out_status) {
   if (!model) {
     nvk_set_error("model handle is NULL");
     return NVK_ERR_INVALID;
@@ -399,7 +429,7 @@ int run_pipelined(nvk_model *model, int kind, int64_t n_reads, const HostBatch &
     return NVK_ERR_INVALID;
   }
   if (n_reads == 0) return NVK_OK;
-  if (!out_status || (kind == JOB_REFINE ? !out_events : !out_ll)) {
+  if (!out_status || !out_main) {
     nvk_set_error("output pointer is NULL");
     return NVK_ERR_INVALID;
   }
@@ -409,10 +439,43 @@ int run_pipelined(nvk_model *model, int kind, int64_t n_reads, const HostBatch &
   if ((rc = check_offsets("context_before", h.cb_off, n_reads))) return rc;
   if ((rc = check_offsets("context_after", h.ca_off, n_reads))) return rc;
   if ((rc = check_offsets("anchors", h.anc_off, n_reads))) return rc;
+  (void)kind;
+  return NVK_OK;
+}
+
+// results of lane L's job to the caller; its verdict is remembered under its ticket
+int collect_ticketed(nvk_pipe_state *p, Lane &L, nvk_ctx *ctx) {
+  if (!L.busy) return NVK_OK;
+  const int64_t t = L.ticket;
+  const int rc = lane_collect(p, L, ctx);
+  if (t >= 0) {
+    Verdict v;
+    v.ticket = t;
+    v.rc = rc;
+    v.err[0] = 0;
+    if (rc) {
+      strncpy(v.err, nvk_last_error(), sizeof v.err - 1);
+      v.err[sizeof v.err - 1] = 0;
+    }
+    try {
+      p->verdicts.push_back(v);
+    } catch (const std::bad_alloc &) {
+    }
+  }
+  return rc;
+}
+
+int run_pipelined(nvk_model *model, int kind, int64_t n_reads, const HostBatch &h, int bandwidth, int mel,
+                  int flag, int32_t *out_events, double *out_ll, int32_t *out_status) {
+  int rc = validate(model, kind, n_reads, h, bandwidth, mel,
+                    kind == JOB_REFINE ? (const void *)out_events : (const void *)out_ll, out_status);
+  if (rc || n_reads == 0) return rc;
   nvk_ctx *ctx = model->ctx;
   NVK_HIP(hipSetDevice(ctx->device));
   nvk_pipe_state *p = nullptr;
   if ((rc = pipe_get(ctx, &p))) return rc;
+  for (int i = 0; i < p->n_lanes; i++)  // batches still in flight from nvk_refine_alignment_submit: deliver them first
+    (void)collect_ticketed(p, p->lanes[i], ctx);
   ctx->last_cells = ctx->last_steps = ctx->last_spill_bytes = 0;
   ctx->last_retries = 0;
   int32_t *ties = nullptr;
@@ -426,23 +489,31 @@ int run_pipelined(nvk_model *model, int kind, int64_t n_reads, const HostBatch &
     p->ties_n = -1;
     ties = p->ties.data();
   }
-  // Chunks: equal shares of the signal (the bulk of the bytes), at least NADAVCA_E2E_MIN_READS reads each so
-  // that a chunk's launches still fill a good part of the chip, and a small batch stays in one piece.
+  // Chunks.  What a single call can hide is bounded by its first upload (nothing to compute yet) and by how
+  // full the chip is while only the early chunks are in flight; so the chunks GROW: a small first one gets the
+  // kernels going early, each later one is NADAVCA_E2E_GROWTH (x100) times its predecessor's share of the signal
+  // bytes.  A chunk has at least NADAVCA_E2E_MIN_READS reads, and a small batch stays in one piece.
   const int64_t total_sig = h.sig_off[n_reads];
-  const int want = env_int("NADAVCA_E2E_CHUNKS", 0, 0, 4096);
   const int64_t min_reads = env_int("NADAVCA_E2E_MIN_READS", 1024, 1, 1 << 30);
-  int64_t n_chunks = want > 0 ? want : (total_sig * 8 + (48ll << 20) - 1) / (48ll << 20);
+  int64_t n_chunks = env_int("NADAVCA_E2E_CHUNKS", 3, 1, 64);
+  if (total_sig * 8 < (int64_t)n_chunks * (8ll << 20)) n_chunks = total_sig * 8 / (8ll << 20);  // (8 MB pieces at least)
   if (n_chunks > n_reads / min_reads) n_chunks = n_reads / min_reads;
   if (n_chunks < 1) n_chunks = 1;
+  const double growth = env_int("NADAVCA_E2E_GROWTH", 200, 100, 1000) / 100.0;
+  double wsum = 0.0, w = 1.0;
+  for (int64_t c = 0; c < n_chunks; c++, w *= growth) wsum += w;
   int64_t lo = 0;
   int first_err = NVK_OK;
   char err_txt[512] = "";
-  for (int64_t c = 0; c < n_chunks && !first_err; c++) {
+  double wacc = 0.0;
+  w = 1.0;
+  for (int64_t c = 0; c < n_chunks && !first_err; c++, w *= growth) {
     int64_t hi;
+    wacc += w;
     if (c == n_chunks - 1) {
       hi = n_reads;
-    } else {  // first read index whose signal offset reaches the c+1-th share
-      const int64_t target = total_sig / n_chunks * (c + 1);
+    } else {  // first read index whose signal offset reaches this chunk's cumulative share
+      const int64_t target = (int64_t)((double)total_sig * (wacc / wsum));
       int64_t x = lo, y = n_reads;
       while (x < y) {
         const int64_t mid = (x + y) >> 1;
@@ -454,6 +525,7 @@ int run_pipelined(nvk_model *model, int kind, int64_t n_reads, const HostBatch &
     if (hi <= lo) continue;
     Lane &L = p->lanes[c % p->n_lanes];
     rc = lane_collect(p, L, ctx);  // the lane's previous chunk: results to the caller, staging free
+    L.ticket = -1;
     if (!rc) rc = lane_submit(p, L, model, h, lo, hi, kind, bandwidth, mel, flag, out_events, out_ll, out_status, ties);
     if (rc) {
       first_err = rc;
@@ -476,7 +548,7 @@ int run_pipelined(nvk_model *model, int kind, int64_t n_reads, const HostBatch &
     int64_t any = 0, nx = 0, nn = 0, nu = 0;
     for (int64_t i = 0; i < n_reads; i++) {
       const int32_t f = p->ties[(size_t)i];
-      any += (f != 0);
+      any += ((f & 7) != 0);  // (bit 3, the plateau mark, is not a tie class)
       nx += (f & NVK_TIE_EXACT) != 0;
       nn += (f & NVK_TIE_NEAR) != 0;
       nu += (f & NVK_TIE_ULP) != 0;
@@ -513,6 +585,65 @@ void nvk_pipe_set_ws_limit(nvk_ctx *ctx, int64_t bytes) {
 }
 void nvk_pipe_forget_ties(nvk_ctx *ctx) {
   if (ctx && ctx->pipe) ctx->pipe->ties_n = -1;
+}
+
+// ---- a stream of batches: upload of batch k+1 and download of batch k-1 behind the kernels of batch k ----------
+extern "C" int nvk_refine_alignment_submit(nvk_model *model, int64_t n_reads, const double *signal,
+                                           const int64_t *sig_off, const int32_t *reference,
+                                           const int64_t *ref_off, const int32_t *ctx_before,
+                                           const int64_t *cb_off, const int32_t *ctx_after,
+                                           const int64_t *ca_off, const int32_t *anchors,
+                                           const int64_t *anc_off, int bandwidth, int min_event_length,
+                                           int model_transitions, int32_t *out_events, int32_t *out_status,
+                                           int32_t *out_tie_flags, int64_t *ticket) {
+  const HostBatch h{signal, sig_off, reference, ref_off, ctx_before, cb_off, ctx_after, ca_off, anchors, anc_off};
+  if (!ticket) {
+    nvk_set_error("ticket pointer is NULL");
+    return NVK_ERR_INVALID;
+  }
+  *ticket = -1;
+  int rc = validate(model, JOB_REFINE, n_reads, h, bandwidth, min_event_length, out_events, out_status);
+  if (rc) return rc;
+  if (n_reads == 0) {
+    nvk_set_error("an empty batch cannot be submitted");
+    return NVK_ERR_INVALID;
+  }
+  nvk_ctx *ctx = model->ctx;
+  NVK_HIP(hipSetDevice(ctx->device));
+  nvk_pipe_state *p = nullptr;
+  if ((rc = pipe_get(ctx, &p))) return rc;
+  const int64_t t = p->next_ticket;
+  Lane &L = p->lanes[t % p->n_lanes];
+  (void)collect_ticketed(p, L, ctx);  // the batch that used this lane before (its verdict waits under its ticket)
+  nvk_pipe_forget_ties(ctx);
+  if ((rc = lane_submit(p, L, model, h, 0, n_reads, JOB_REFINE, bandwidth, min_event_length,
+                        model_transitions ? 1 : 0, out_events, nullptr, out_status, out_tie_flags)))
+    return rc;
+  L.ticket = t;
+  p->next_ticket = t + 1;
+  *ticket = t;
+  return NVK_OK;
+}
+
+extern "C" int nvk_refine_alignment_wait(nvk_model *model, int64_t ticket) {
+  if (!model || !model->ctx->pipe || ticket < 0 || ticket >= model->ctx->pipe->next_ticket) {
+    nvk_set_error("nvk_refine_alignment_wait: no such ticket");
+    return NVK_ERR_INVALID;
+  }
+  nvk_ctx *ctx = model->ctx;
+  NVK_HIP(hipSetDevice(ctx->device));
+  nvk_pipe_state *p = ctx->pipe;
+  Lane &L = p->lanes[ticket % p->n_lanes];
+  if (L.busy && L.ticket == ticket) (void)collect_ticketed(p, L, ctx);
+  for (size_t i = 0; i < p->verdicts.size(); i++)
+    if (p->verdicts[i].ticket == ticket) {
+      const Verdict v = p->verdicts[i];
+      p->verdicts.erase(p->verdicts.begin() + (long)i);
+      if (v.rc) nvk_set_error("%s", v.err);
+      return v.rc;
+    }
+  nvk_set_error("nvk_refine_alignment_wait: ticket %lld was already waited for", (long long)ticket);
+  return NVK_ERR_INVALID;
 }
 
 extern "C" int nvk_refine_alignment_batch(nvk_model *model, int64_t n_reads, const double *signal,

@@ -132,6 +132,31 @@ def normalize_groups_dev(context, raw, grp_off, out=None):
     return out, cs
 
 
+def select_hist_dev(context, x):
+    """-> local_hist(mode, centre, prefix, pass) over a device tensor of samples, for distributed.pooled_median:
+    256 counts per call (int64 cuda tensor, ready for the all-reduce), nvk_select_hist_dev."""
+    import torch
+    lib = _lib.load()
+
+    def local_hist(mode, centre, prefix, p):
+        h = torch.zeros(256, dtype=torch.int64, device=x.device)
+        _lib.check(lib.nvk_select_hist_dev(context.handle, _dp(x), int(x.numel()), int(mode), float(centre),
+                                           C.c_uint64(int(prefix)), int(p), _dp(h)), 'nvk_select_hist_dev')
+        return h
+    return local_hist
+
+
+def normalize_apply_dev(context, x, centre, scale, out=None):
+    """clip((x - centre) / scale, -5, 5) on the device (read.py:80-81 with a given shift and scale)."""
+    import torch
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.check(lib.nvk_normalize_apply_dev(context.handle, _dp(x), int(x.numel()), float(centre), float(scale),
+                                           _dp(out)), 'nvk_normalize_apply_dev')
+    return out
+
+
 def expected_levels_dev(dbatch, kmer_model, with_contexts=True):
     """``KmerModel.get_expected_signal`` for every read of the batch -> f64 (sum R,).  Without contexts
     the k-mers at the ends are padded with base 0, as ``get_expected_signal(bases, [], [])`` does

@@ -188,6 +188,40 @@ def refine_alignment_flat(batch, bandwidth, min_event_length, kmer_model, model_
     return events, status
 
 
+class RefineStream:
+    """``refine_alignment`` over a stream of FlatBatches with the PCIe copies behind the kernels
+    (nvk_refine_alignment_submit / _wait, include/nadavca_hip.h): ``submit`` uploads a batch and returns at once
+    while the previous batch's kernels still run, ``wait`` hands back (events, status, tie flags) of a ticket.
+    Keep at most a few batches in flight (one lane each; the library has three)."""
+
+    def __init__(self, kmer_model, bandwidth, min_event_length, model_transitions):
+        self._lib = _lib.load()
+        self.kmer_model = kmer_model
+        self.args = (int(bandwidth), int(min_event_length), int(bool(model_transitions)))
+        self._pending = {}
+
+    def submit(self, batch, out=None):
+        """``out``: (events int32 (sum R, 2), status int32 (n,), tie flags int32 (n,)) arrays to reuse — fresh
+        arrays are page-faulted in while the results arrive, which shows in a tight loop."""
+        if out is None:
+            out = (np.zeros((int(batch.ref_off[-1]), 2), dtype=np.int32), np.zeros(batch.n, dtype=np.int32),
+                   np.zeros(batch.n, dtype=np.int32))
+        events, status, ties = out
+        assert events.size == 2 * int(batch.ref_off[-1]) and status.size == batch.n and ties.size == batch.n
+        t = C.c_int64(-1)
+        _lib.check(self._lib.nvk_refine_alignment_submit(self.kmer_model.handle, batch.n, *batch.pointers(),
+                                                         *self.args, _ptr(events), _ptr(status), _ptr(ties),
+                                                         C.byref(t)), 'nvk_refine_alignment_submit')
+        self._pending[t.value] = (batch, events, status, ties)   # (keeps the host arrays alive until wait)
+        return t.value
+
+    def wait(self, ticket):
+        batch, events, status, ties = self._pending.pop(ticket)
+        _lib.check(self._lib.nvk_refine_alignment_wait(self.kmer_model.handle, int(ticket)),
+                   'nvk_refine_alignment_wait')
+        return events, status, ties
+
+
 def estimate_log_likelihoods_flat(batch, bandwidth, min_event_length, kmer_model, model_wobbling,
                                   on_error='raise'):
     """-> (ll f64 (sum R, alphabet), status int32 (n,)) for a FlatBatch."""

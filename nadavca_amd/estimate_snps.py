@@ -57,6 +57,24 @@ def estimate_snps(reference_filename, reads, reference=None, config=defaults.CON
     return estimator.estimate_probabilities(reference, reads)
 
 
+def _check_status(what, status, live):
+    """Per-read failures of a batch kernel (device tensor of NVK_READ_* codes): invalid input raises ValueError
+    with the reads' indices in the ReadBatch; a band wider than the compiled kernels serve (READ_TOO_WIDE, a
+    capability limit of this build, not bad input) only drops that read — it stays out of the sums like a read
+    without a path — with a note on stderr."""
+    from ._lib import READ_TOO_WIDE
+    if not bool((status < 0).any()):
+        return
+    import torch
+    wide = status == READ_TOO_WIDE
+    bad = torch.nonzero((status < 0) & ~wide).reshape(-1)[:8]
+    if bad.numel():
+        raise ValueError('%s: invalid input for read(s) %s (status %s)'
+                         % (what, live[bad].tolist(), status[bad].tolist()))
+    sys.stderr.write('%s: %d read(s) skipped, band wider than the compiled kernels serve (first: %s)\n'
+                     % (what, int(wide.sum()), live[torch.nonzero(wide).reshape(-1)[:8]].tolist()))
+
+
 class IndependentChunks:
     """``estimate_snps(independent=True)`` for a batch: one chunk per read that produced one, as arrays —
     read ``reads[j]`` covers reference positions [start[j], end[j]) and has posterior rows
@@ -73,7 +91,8 @@ class IndependentChunks:
 
 
 def estimate_snps_batch(reference_num, read_batch, config=defaults.CONFIG_FILE,
-                        kmer_model=defaults.KMER_MODEL_FILE, independent=False, aligner=None, fit_workers=0):
+                        kmer_model=defaults.KMER_MODEL_FILE, independent=False, aligner=None, fit_workers=0,
+                        group=None, distributed=None, dst=0):
     """``estimate_snps`` for a struct-of-arrays ``ReadBatch`` (nadavca_amd/readbatch.py) without per-read
     Python: the steps of estimate_snps.py:57-70 and estimator.py:59-121,199-236 — ONE median/MAD over all
     reads, approximate alignment, the spline tweak (pre-alignment without transition rows, expected levels,
@@ -81,7 +100,15 @@ def estimate_snps_batch(reference_num, read_batch, config=defaults.CONFIG_FILE,
     device), log-likelihoods, normalise / strand-flip / per-position sum, grouping, posterior — with the
     signals, the sums and everything between them resident on the device.
     ``reference_num``: the reference as base codes; ``aligner``: as for ``align_signal_batch``.
-    -> list of Chunk (consensus) or IndependentChunks."""
+    -> list of Chunk (consensus) or IndependentChunks.
+
+    Several GPUs (``distributed=True``, or a ``group``; default: whenever torch.distributed is initialised with
+    more than one rank): every rank passes ITS shard of the reads as ``read_batch`` and the two exchange steps of
+    the path run over torch.distributed (RCCL over xGMI with the nccl backend) — the pooled median / MAD of
+    estimate_snps.py:61 as an exact distributed selection (256 counts per pass cross ranks, distributed.py:
+    pooled_centre_scale), and for ``independent=False`` ONE reduce(sum) of the packed per-position sums plus a
+    small all-gather of the chunk intervals.  The consensus Chunk list is returned on rank ``dst`` (None
+    elsewhere); ``independent=True`` returns every rank's own IndependentChunks."""
     import numpy
     import torch
     from . import readbatch, splinefit
@@ -106,15 +133,34 @@ def estimate_snps_batch(reference_num, read_batch, config=defaults.CONFIG_FILE,
     if raw.dtype != torch.float64:
         raw = raw.to(torch.float64)
     total = int(rb.sig_off[-1])
-    one_group = torch.tensor([0, total], dtype=torch.int64, device=device)
-    norm, _ = normalize_groups_dev(context, raw, one_group, out=raw)   # all reads pooled (estimate_snps.py:61)
+    if distributed is None:
+        distributed = group is not None
+        if not distributed:
+            import torch.distributed as tdist
+            distributed = tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1
+    if distributed:
+        from . import distributed as D
+        from .device import select_hist_dev, normalize_apply_dev
+        # all reads of ALL ranks pooled (estimate_snps.py:61): exact distributed median and MAD
+        centre, scale = D.pooled_centre_scale(select_hist_dev(context, raw), total, device=device, group=group)
+        norm = normalize_apply_dev(context, raw, centre, scale, out=raw)
+    else:
+        one_group = torch.tensor([0, total], dtype=torch.int64, device=device)
+        norm, _ = normalize_groups_dev(context, raw, one_group, out=raw)   # all reads pooled (estimate_snps.py:61)
     ba = aligner.get_base_alignments(rb)
     sa = readbatch.signal_alignments(rb, ba, bw, reference_num, kmer_model.get_k(),
                                      kmer_model.get_central_position(), device=device)
     n_live = int(sa.live.numel())
     if n_live == 0:
-        return IndependentChunks(numpy.zeros(0, dtype=numpy.int64), *[numpy.zeros(0)] * 3,
-                                 numpy.zeros(1, dtype=numpy.int64)) if independent else []
+        if independent:
+            return IndependentChunks(numpy.zeros(0, dtype=numpy.int64), *[numpy.zeros(0)] * 3,
+                                     numpy.zeros(1, dtype=numpy.int64))
+        if not distributed:
+            return []
+        # (a rank whose shard aligned nowhere still takes part in the exchange, with empty sums)
+        acc = torch.zeros((L, kmer_model.alphabet_size), dtype=torch.float64, device=device)
+        cov = torch.zeros(L, dtype=torch.int64, device=device)
+        return _consensus_chunks(context, kmer_model, config, reference_num, acc, cov, [], device, True, group, dst)
     dbatch = DeviceBatch.from_windows(norm, sa, device)
     if config['tweak_signal_normalization']:
         # read.py:83-94: pre-alignment without transition rows, expected levels, per-event means (kernels);
@@ -146,9 +192,7 @@ def estimate_snps_batch(reference_num, read_batch, config=defaults.CONFIG_FILE,
             tweaked[keep] = dbatch.signal[keep]
         dbatch.signal = tweaked
     ll, status = estimate_log_likelihoods_dev(dbatch, bw, mel, kmer_model, config['model_wobbling'])
-    if bool((status < 0).any()):
-        bad = torch.nonzero(status < 0).reshape(-1)[:8]
-        raise ValueError('estimate_log_likelihoods: invalid input for read(s) %s' % sa.live[bad].tolist())
+    _check_status('estimate_log_likelihoods', status, sa.live)
     rev32 = sa.reverse.to(torch.int32)
     nel = config['normalization_event_length']
     k, prior = kmer_model.get_k(), config['snp_prior_probability']
@@ -169,9 +213,29 @@ def estimate_snps_batch(reference_num, read_batch, config=defaults.CONFIG_FILE,
         return _independent_result(sa, okh, off, post.cpu().numpy())
     acc, cov = consensus_accumulate_dev(context, dbatch, ll, sa.ref_start.contiguous(), rev32, status, nel, L)
     starts, ends = sa.ref_start[ok].cpu().numpy(), sa.ref_end[ok].cpu().numpy()
-    groups = ProbabilityEstimator.group_ranges(list(zip(starts.tolist(), ends.tolist())))
+    return _consensus_chunks(context, kmer_model, config, reference_num, acc, cov,
+                             list(zip(starts.tolist(), ends.tolist())), device, distributed, group, dst)
+
+
+def _consensus_chunks(context, kmer_model, config, reference_num, acc, cov, ranges, device, distributed, group, dst):
+    """Per-position sums -> grouped posteriors (estimator.py:205-236).  Distributed: the sums of all ranks meet in
+    ONE reduce of the packed device buffer, the intervals in a small all-gather; the posterior runs on ``dst``."""
+    import numpy
+    import torch
+    from .device import posterior_segments_dev
+    from .estimator import ProbabilityEstimator
+    if distributed:
+        from . import distributed as D
+        ranges = D.gather_ranges(ranges, device=device, group=group)
+        tot = D.reduce_consensus_tensors(acc, cov, dst=dst, group=group)
+        if tot is None:
+            return None
+        acc, cov = tot
+    groups = ProbabilityEstimator.group_ranges(ranges)
     if not groups:
         return []
+    k, prior = kmer_model.get_k(), config['snp_prior_probability']
+    ref_dev = torch.from_numpy(numpy.ascontiguousarray(reference_num, dtype=numpy.int32)).to(device)
     seg = numpy.concatenate([[0], numpy.cumsum([e - s for s, e in groups])]).astype(numpy.int64)
     pos = torch.from_numpy(numpy.concatenate([numpy.arange(s, e) for s, e in groups])).to(device)
     post = posterior_segments_dev(context, acc[pos], ref_dev[pos], torch.from_numpy(seg).to(device), k, prior)

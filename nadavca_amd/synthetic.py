@@ -132,11 +132,40 @@ def make_batch(n_reads, model, seed=0, R=400, R_spread=40, **kw):
     return Batch(cases)
 
 
+def tile_batch(batch, n):
+    """``batch`` repeated to ``n`` reads (whole copies, then a prefix): BASELINE config 4 asks for 200 000 reads, and
+    simulating each of them in Python would take minutes; throughput does not care that read i + len(batch) is
+    read i again.  ``cases`` stays the unique list (the CPU baseline samples from it)."""
+    if n <= batch.n:
+        return Batch(batch.cases[:n])
+    reps, rem = divmod(n, batch.n)
+    head = Batch(batch.cases[:rem]) if rem else None
+    out = Batch.__new__(Batch)
+    out.n, out.cases = n, batch.cases
+
+    def rep(name):
+        parts = [getattr(batch, name)] * reps + ([getattr(head, name)] if head is not None else [])
+        return np.concatenate(parts)
+
+    def rep_off(name):
+        off = getattr(batch, name)
+        lens = np.diff(off)
+        lens = np.concatenate([lens] * reps + ([np.diff(getattr(head, name))] if head is not None else []))
+        return np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+
+    for a, o in (('signal', 'sig_off'), ('reference', 'ref_off'), ('context_before', 'cb_off'),
+                 ('context_after', 'ca_off'), ('anchors', 'anc_off')):
+        setattr(out, a, rep(a))
+        setattr(out, o, rep_off(o))
+    return out
+
+
 # BASELINE.json configs 2-5 (sizes: SURVEY.md §8 header)
 WORKLOADS = {
     'cfg2_align': dict(n_reads=10000, R=400, R_spread=40, bandwidth=150),
     'cfg3_snps': dict(n_reads=10000, R=400, R_spread=40, bandwidth=150),
-    'cfg4_consensus': dict(n_reads=10000, R=400, R_spread=40, bandwidth=150, reference_length=10000),
+    # (n_reads: the whole job's 200 000 reads; bench.py gives every rank 200 000 / world of them)
+    'cfg4_consensus': dict(n_reads=200000, R=400, R_spread=40, bandwidth=150, reference_length=10000),
     'cfg5_long': dict(n_reads=64, R=5000, R_spread=500, bandwidth=1000),
 }
 

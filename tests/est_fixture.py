@@ -1,6 +1,6 @@
 """Helpers shared by the estimator-level tests: rebuild the simulated reads stored in
-tests/golden/estimator.npz (written by oracle/make_golden_estimator.py from the reference's own
-Python layer) with this package's classes."""
+tests/golden/estimator.npz and tests/golden/workflows.npz (written by oracle/make_golden_estimator.py and
+oracle/make_golden_workflows.py from the reference's own Python layer) with this package's classes."""
 import json
 import os
 
@@ -10,8 +10,8 @@ from conftest import GOLDEN
 
 
 class EstimatorFixture:
-    def __init__(self):
-        z = np.load(os.path.join(GOLDEN, 'estimator.npz'), allow_pickle=False)
+    def __init__(self, name='estimator.npz'):
+        z = np.load(os.path.join(GOLDEN, name), allow_pickle=False)
         self.z = z
         self.config = json.loads(str(z['config']))
         self.genome = np.array(list(str(z['genome'])))

@@ -131,3 +131,40 @@ def test_shard_bounds_cover_everything():
             assert b[0][0] == 0 and b[-1][1] == n
             assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
             assert max(h - l for l, h in b) - min(h - l for l, h in b) <= 1
+
+
+def _median_worker(rank, world, port, tmp):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from nadavca_amd import distributed as D
+    out = []
+    for case, x in enumerate(_median_cases()):
+        lo, hi = D.shard_bounds(x.size, rank, world) if case != 3 else ((0, x.size) if rank == 0 else (0, 0))
+        mine = x[lo:hi]                                       # (case 3: one rank holds nothing)
+        out.append(D.pooled_centre_scale(D.numpy_hist(mine), mine.size))
+    np.save(os.path.join(tmp, 'median_r%d.npy' % rank), np.array(out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _median_cases():
+    rng = np.random.default_rng(99)
+    adc = np.rint(12.0 * rng.normal(0.0, 1.3, 40001) + 90.0)          # ADC counts: heavy duplication, odd count
+    return [adc, adc[:-1].copy(), rng.normal(0.0, 1.0, 1000) * 1e-3, adc[:257].copy(),
+            np.concatenate([rng.normal(0, 1, 64), [0.0, -0.0, 5e300, -5e300]])]
+
+
+def test_two_rank_pooled_median_and_mad_equal_numpy(tmp_path):
+    """estimate_snps normalises ALL reads with one median / MAD (estimate_snps.py:61, read.py:68-81).  With the
+    samples sharded over ranks that is an exact distributed selection: per radix pass only 256 counts cross ranks
+    (distributed.pooled_centre_scale; on the GPU the counts come from nvk_select_hist_dev).  Two gloo ranks on CPU
+    tensors: shift and scale bit-equal to numpy.median over the union, on both ranks."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_median_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / 'median_r0.npy'), np.load(tmp_path / 'median_r1.npy')
+    assert np.array_equal(r0, r1)
+    for (c, s), x in zip(r0, _median_cases()):
+        assert c == np.median(x) and s == np.median(np.abs(x - c))

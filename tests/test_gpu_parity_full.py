@@ -41,7 +41,7 @@ def _same(ev, exp):
     return ev.shape == exp.shape and np.array_equal(ev, exp)
 
 
-TIE_EXACT, TIE_NEAR, TIE_ULP = 1, 2, 4   # include/nadavca_hip.h
+TIE_EXACT, TIE_NEAR, TIE_ULP, TIE_PLATEAU = 1, 2, 4, 8   # include/nadavca_hip.h
 TIE_LOOSE = TIE_NEAR | TIE_ULP           # the contract: without these two bits a read equals the reference
 
 
@@ -72,11 +72,11 @@ def test_config2_bench_batch_every_read_equals_the_oracle(oracle_port):
         assert diff == [], 'transitions=%s: %d of %d reads differ from the oracle, first %s' % (tr, len(diff), n, diff[:5])
         st = ctx.last_batch_stats()
         n_x, n_u, n_n = _tie_counts(flags)
-        assert int((flags != 0).sum()) == st['reads_tie_ambiguous']
+        assert int(((flags & 7) != 0).sum()) == st['reads_tie_ambiguous']
         assert (n_x, n_u, n_n) == (st['reads_tie_exact'], st['reads_tie_ulp'], st['reads_tie_near'])
         assert (n_u + n_n) * 100 < n, 'ties on %d of %d reads' % (n_u + n_n, n)
-        print('cfg2 transitions=%s: 0 of %d reads differ; reads with tie bits: %d exact, %d ulp, %d near'
-              % (tr, n, n_x, n_u, n_n))
+        print('cfg2 transitions=%s: 0 of %d reads differ; reads with tie bits: %d exact, %d ulp, %d near; plateau mark: %d'
+              % (tr, n, n_x, n_u, n_n, int(((flags & TIE_PLATEAU) != 0).sum())))
         # ... and against the reference's OWN code (oracle/_ref, compiled in place from /root/reference and
         # shipped to the GPU box) on a 500-read slice
         from oracle.oracle import Oracle, have_reference
@@ -133,7 +133,7 @@ def _fuzz_contract(make_batch, seed, iters, oracle_port, label, max_diff_share):
     from fuzz_cases import reads_of, classify_difference
     from nadavca_amd import dtw, _lib
     ctx = _lib.default_context()
-    n_reads = n_diff = n_x = n_n = n_u = n_diff_no_ulp = 0
+    n_reads = n_diff = n_x = n_n = n_u = n_diff_no_ulp = n_p = 0
     why_count = {}
     for it in range(iters):
         fb = make_batch(seed, it)
@@ -151,6 +151,7 @@ def _fuzz_contract(make_batch, seed, iters, oracle_port, label, max_diff_share):
             n_x += int((flags[j] & TIE_EXACT) != 0)
             n_n += int((flags[j] & TIE_NEAR) != 0)
             n_u += int((flags[j] & TIE_ULP) != 0)
+            n_p += int((flags[j] & TIE_PLATEAU) != 0)
             if not same:
                 n_diff += 1
                 n_diff_no_ulp += int((flags[j] & TIE_ULP) == 0)
@@ -158,11 +159,13 @@ def _fuzz_contract(make_batch, seed, iters, oracle_port, label, max_diff_share):
                 why = classify_difference(got[j], exp, c, fb['model'], k, central, alphabet, fb['bw'], fb['mel'],
                                           fb['tr'])
                 assert why != 'UNEXPLAINED', ('unexplained difference', it, j)
+                if why == 'flat-plateau':   # ... and the read is marked as holding such a boundary
+                    assert flags[j] & TIE_PLATEAU, ('flat-plateau difference without the plateau mark', it, j)
                 why_count[why] = why_count.get(why, 0) + 1
         mg.close()
     assert n_diff <= max_diff_share * n_reads, (n_diff, n_reads)
-    print('%s: %d reads, reads with tie bits %d exact / %d ulp / %d near, %d differ (%d of them without the ulp bit) %s'
-          % (label, n_reads, n_x, n_u, n_n, n_diff, n_diff_no_ulp, why_count))
+    print('%s: %d reads, reads with tie bits %d exact / %d ulp / %d near, %d with the plateau mark; %d differ (%d of them '
+          'without the ulp bit) %s' % (label, n_reads, n_x, n_u, n_n, n_p, n_diff, n_diff_no_ulp, why_count))
 
 
 def test_random_models_contract(oracle_port):
@@ -253,8 +256,8 @@ def test_config2_quantised_to_adc_steps_every_read_equals_the_oracle(oracle_port
         exp = _oracle_refine(oracle_port, mo, batch.cases, wl['bandwidth'], 2, tr)
         diff = [i for i in range(n) if not _same(got[i], exp[i])]
         n_x, n_u, n_n = _tie_counts(flags)
-        print('cfg2 quantised, transitions=%s: %d of %d reads differ; reads with tie bits: %d exact, %d ulp, %d near'
-              % (tr, len(diff), n, n_x, n_u, n_n))
+        print('cfg2 quantised, transitions=%s: %d of %d reads differ; reads with tie bits: %d exact, %d ulp, %d near; '
+              'plateau mark: %d' % (tr, len(diff), n, n_x, n_u, n_n, int(((flags & TIE_PLATEAU) != 0).sum())))
         assert diff == [], (tr, diff[:5])
 
 

@@ -24,9 +24,10 @@ torch.cuda.synchronize()
 res_ms = (time.perf_counter() - t) / 5 * 1e3
 print('resident: %.2f ms' % res_ms, flush=True)
 want = ev0.cpu().numpy()
-for lanes, chunks in [(1, 1), (2, 2), (2, 4), (3, 4), (3, 6), (3, 8), (4, 8), (4, 12), (4, 16), (3, 12)]:
+def run(lanes, chunks, growth):
     os.environ['NADAVCA_E2E_LANES'] = str(lanes)
     os.environ['NADAVCA_E2E_CHUNKS'] = str(chunks)
+    os.environ['NADAVCA_E2E_GROWTH'] = str(growth)
     os.environ['NADAVCA_E2E_MIN_READS'] = '1'
     c2 = _lib.Context(0)
     k2 = dtw.KmerModel(*model, context=c2)
@@ -37,5 +38,40 @@ for lanes, chunks in [(1, 1), (2, 2), (2, 4), (3, 4), (3, 6), (3, 8), (4, 8), (4
         t = time.perf_counter()
         dtw.refine_alignment_flat(flat, 150, 2, k2, True)
         ts.append((time.perf_counter() - t) * 1e3)
-    print('lanes %d chunks %2d: e2e %.2f ms (min %.2f)  = %.2fx resident' % (lanes, chunks, float(np.median(ts)), min(ts), float(np.median(ts)) / res_ms), flush=True)
+    print('lanes %d chunks %2d growth %.2f: single call e2e %.2f ms (min %.2f) = %.2fx resident'
+          % (lanes, chunks, growth / 100, float(np.median(ts)), min(ts), float(np.median(ts)) / res_ms), flush=True)
+    return c2, k2
+
+
+for cfg in [(1, 1, 100), (2, 2, 100), (2, 2, 200), (2, 2, 300), (3, 3, 150), (3, 3, 200), (3, 3, 300), (3, 4, 150),
+            (3, 4, 200), (4, 4, 200), (4, 5, 170), (3, 5, 170), (2, 3, 200), (2, 4, 200)]:
+    c2, k2 = run(*cfg)
+    k2.close(); c2.close()
+
+# a stream of batches (submit / wait): steady state
+for lanes in (2, 3):
+    os.environ['NADAVCA_E2E_LANES'] = str(lanes)
+    c2 = _lib.Context(0)
+    k2 = dtw.KmerModel(*model, context=c2)
+    rs = dtw.RefineStream(k2, 150, 2, True)
+    outs = [(np.zeros((int(flat.ref_off[-1]), 2), np.int32), np.zeros(flat.n, np.int32), np.zeros(flat.n, np.int32))
+            for _ in range(lanes)]
+    for depth in range(1, lanes + 1):
+        for rep in range(2):
+            K = 8
+            t = time.perf_counter()
+            tk = []
+            for i in range(K):
+                tk.append(rs.submit(flat, out=outs[i % lanes]))
+                if i >= depth - 1 and depth > 0:
+                    j = i - (depth - 1)
+                    ev, st, ti = rs.wait(tk[j])
+                    if depth > 1 or True:
+                        pass
+            # (everything waited for when depth == 1; else the tail)
+            for j in range(K - (depth - 1), K):
+                ev, st, ti = rs.wait(tk[j])
+            dt = (time.perf_counter() - t) / K * 1e3
+        assert np.array_equal(ev, want)
+        print('stream lanes %d in-flight %d: %.2f ms per batch = %.2fx resident' % (lanes, depth, dt, dt / res_ms), flush=True)
     k2.close(); c2.close()
