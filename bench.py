@@ -140,6 +140,8 @@ def main():
     ap.add_argument('--fit-workers', type=int, default=16, help='api_estimate_snps: processes for the spline fits')
     ap.add_argument('--reads', type=int, default=0, help='reads per GPU per step (default: the config size)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-e2e', action='store_true', help='skip the host-pointer legs (profiling runs: their launches '
+                    'would be averaged into the kernel statistics)')
     ap.add_argument('--slots', type=int, default=0)
     ap.add_argument('--k', type=int, default=0, help='use a synthetic k-mer table of this size (e.g. 10: the size of the '
                     "reference's coded default table, 4^10 rows) instead of the packaged 6-mer table")
@@ -366,7 +368,7 @@ def main():
             out['roofline'] = rl
         elif is_api:
             out['kernels_ms_per_step'] = {k: v[0] / args.steps for k, v in timing.items() if v[1]}
-        if wname == 'cfg2_align' and world == 1:
+        if wname == 'cfg2_align' and world == 1 and not args.no_e2e:
             # T_e2e: host arrays in -> host arrays out, every PCIe copy inside the timed region.
             # (a) a STREAM of batches through nvk_refine_alignment_submit / _wait, two in flight: the upload of
             #     batch k+1 and the download of batch k-1 run behind the kernels of batch k (csrc/pipeline.hip);

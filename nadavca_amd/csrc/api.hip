@@ -140,6 +140,7 @@ extern "C" void nvk_ctx_destroy(nvk_ctx *ctx) {
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+  if (ctx->h_plan) (void)hipHostFree(ctx->h_plan);
   if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -439,8 +440,18 @@ int check_common(nvk_model *model, int64_t n_reads, int bandwidth, int mel) {
   return NVK_OK;
 }
 
-// plan a batch: metas + row table in ctx workspaces, totals read back to the host
-int plan_batch(nvk_model *model, const BatchArgs &a, int mode, int wobbling, PlanTotals &tot) {
+// What the planner hands back to the host, in one pinned block: the totals, then (refine_alignment) the reads'
+// step counts in launch order.
+struct PlanHost {
+  PlanTotals tot;
+  int32_t steps[1];  // [n_reads]
+};
+
+// plan a batch: metas + row table (+ for refine_alignment the lane records of kernels_align3, the launch order
+// and the step counts in that order) in ctx workspaces; ONE copy + synchronisation brings the totals and the
+// step counts to the host (ctx->h_plan)
+int plan_batch(nvk_model *model, const BatchArgs &a, int mode, int wobbling, PlanTotals &tot, const int **order,
+               const int32_t **steps_sorted) {
   nvk_ctx *ctx = model->ctx;
   int64_t n = a.n_reads;
   int64_t rows_total = (mode == PLAN_ALIGN_TRANS) ? 2 * a.total_ref : a.total_ref + n;
@@ -449,12 +460,38 @@ int plan_batch(nvk_model *model, const BatchArgs &a, int mode, int wobbling, Pla
   if ((rc = nvk_ws_reserve(ctx, WS_ROWS, (size_t)(rows_total + 1) * sizeof(RowParam)))) return rc;
   if ((rc = nvk_ws_reserve(ctx, WS_BANDTMP, (size_t)(2 * (a.total_ref + n) + 2) * 8))) return rc;
   if ((rc = nvk_ws_reserve(ctx, WS_MISC, 256))) return rc;
+  if ((rc = nvk_ws_reserve(ctx, WS_LANE_F, (size_t)(rows_total + 1) * 48))) return rc;   // sizeof(Lane3), lane3.h
+  if ((rc = nvk_ws_reserve(ctx, WS_LANE_R, (size_t)(rows_total + 1) * 48))) return rc;
+  if ((rc = nvk_ws_reserve(ctx, WS_OFFS, (size_t)(rows_total + 1) * sizeof(int32_t)))) return rc;
+  if ((rc = nvk_ws_reserve(ctx, WS_STEPS, (size_t)(n + 1) * sizeof(int32_t)))) return rc;
+  const size_t hbytes = sizeof(PlanHost) + (size_t)n * sizeof(int32_t);
+  if (hbytes > ctx->h_plan_cap) {
+    if (ctx->h_plan) (void)hipHostFree(ctx->h_plan);
+    ctx->h_plan = nullptr;
+    ctx->h_plan_cap = 0;
+    if (hipHostMalloc(&ctx->h_plan, hbytes + hbytes / 4, hipHostMallocDefault) != hipSuccess) {
+      ctx->h_plan = nullptr;
+      nvk_set_error("hipHostMalloc of %zu bytes failed", hbytes);
+      return NVK_ERR_NOMEM;
+    }
+    ctx->h_plan_cap = hbytes + hbytes / 4;
+  }
+  PlanHost *hp = (PlanHost *)ctx->h_plan;
   PlanTotals *d_tot = (PlanTotals *)((char *)ctx->ws[WS_MISC] + 64);
   rc = launch_plan(ctx, model->dm, a, mode, wobbling, (ReadMeta *)ctx->ws[WS_META],
-                   (RowParam *)ctx->ws[WS_ROWS], (unsigned long long *)ctx->ws[WS_BANDTMP], d_tot);
+                   (RowParam *)ctx->ws[WS_ROWS], (unsigned long long *)ctx->ws[WS_BANDTMP], d_tot,
+                   ctx->ws[WS_LANE_F], ctx->ws[WS_LANE_R], (int32_t *)ctx->ws[WS_OFFS]);
   if (rc) return rc;
-  NVK_HIP(hipMemcpyAsync(&tot, d_tot, sizeof(PlanTotals), hipMemcpyDeviceToHost, ctx->stream));
+  int *ord = nullptr;
+  rc = launch_order(ctx, (const ReadMeta *)ctx->ws[WS_META], n, d_tot, &ord, (int32_t *)ctx->ws[WS_STEPS]);
+  if (rc) return rc;
+  NVK_HIP(hipMemcpyAsync(&hp->tot, d_tot, sizeof(PlanTotals), hipMemcpyDeviceToHost, ctx->stream));
+  if (n) NVK_HIP(hipMemcpyAsync(hp->steps, ctx->ws[WS_STEPS], (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost,
+                                ctx->stream));
   NVK_HIP(hipStreamSynchronize(ctx->stream));
+  tot = hp->tot;
+  *order = ord;
+  *steps_sorted = hp->steps;
   ctx->last_cells = (int64_t)tot.cells;
   ctx->last_steps = (int64_t)tot.steps;
   return NVK_OK;
@@ -557,23 +594,38 @@ extern "C" int nvk_refine_alignment_batch_dev(
   ctx->last_retries = 0;
   ctx->last_ties = ctx->last_ties_exact = ctx->last_ties_near = ctx->last_ties_ulp = 0;
   nvk_pipe_forget_ties(ctx);
-  rc = plan_batch(model, a, model_transitions ? PLAN_ALIGN_TRANS : PLAN_ALIGN_PLAIN, 0, tot);
+  const int *order = nullptr;
+  const int32_t *steps_sorted = nullptr;
+  rc = plan_batch(model, a, model_transitions ? PLAN_ALIGN_TRANS : PLAN_ALIGN_PLAIN, 0, tot, &order, &steps_sorted);
   if (rc) return rc;
+  // WS_TIES: per-read tie bits, then 4 class counts, then the number of reads handed to the exact kernel
   if ((rc = nvk_ws_reserve(ctx, WS_TIES, (size_t)(n_reads + 8) * sizeof(int32_t)))) return rc;
   NVK_HIP(hipMemsetAsync(ctx->ws[WS_TIES], 0, (size_t)(n_reads + 8) * sizeof(int32_t), ctx->stream));
   ctx->ties_n = n_reads;
+  int32_t *d_ties = (int32_t *)ctx->ws[WS_TIES];
+  int *d_retry = (int *)(d_ties + n_reads + 4);
   const ReadMeta *metas = (const ReadMeta *)ctx->ws[WS_META];
   const RowParam *rows = (const RowParam *)ctx->ws[WS_ROWS];
   bool exact_all = force && force[0] == '1';
+  // reads in which a path decision fell inside the tie margin (include/nadavca_hip.h) and — one copy, one
+  // synchronisation for both — the reads the fast kernel handed to the exact one
+  int32_t tail[5] = {0, 0, 0, 0, 0};
+  auto fetch_counts = [&]() -> int {
+    int rc2 = launch_count_flags(ctx, d_ties, n_reads, d_ties + n_reads);
+    if (rc2) return rc2;
+    NVK_HIP(hipMemcpyAsync(tail, d_ties + n_reads, sizeof tail, hipMemcpyDeviceToHost, ctx->stream));
+    NVK_HIP(hipStreamSynchronize(ctx->stream));
+    return NVK_OK;
+  };
   if (!exact_all) {
     // fast path: plain doubles under a wave-uniform scale (bit-identical while in range);
     // reads it cannot serve come back flagged and are redone by the exact kernel below
-    int n_retry = 0;
-    rc = launch_align3(ctx, a, model_transitions ? 1 : 0, metas, rows, tot, out_events, out_status,
-                       &n_retry);
-    ctx->last_retries = n_retry;
+    rc = launch_align3(ctx, a, model_transitions ? 1 : 0, metas, rows, tot, order, steps_sorted, out_events,
+                       out_status, d_retry);
     if (rc) return rc;
-    bool redo = n_retry > 0;
+    if ((rc = fetch_counts())) return rc;
+    ctx->last_retries = tail[4];
+    bool redo = tail[4] > 0;
 #ifdef NVK_DEBUG_SWITCHES
     if (getenv("NADAVCA_ALIGN3_NORETRY")) redo = false;  // debug builds only: leave the flags visible
 #endif
@@ -581,24 +633,17 @@ extern "C" int nvk_refine_alignment_batch_dev(
       rc = launch_align_retry(ctx, a, model_transitions ? 1 : 0, metas, rows, tot, out_events,
                               out_status);
       if (rc) return rc;
+      if ((rc = fetch_counts())) return rc;
     }
   } else {
     rc = launch_align(ctx, a, model_transitions ? 1 : 0, metas, rows, tot, out_events, out_status);
     if (rc) return rc;
+    if ((rc = fetch_counts())) return rc;
   }
-  {  // reads in which a path decision fell inside the comparison tolerance (include/nadavca_hip.h)
-    int32_t *d_ties = (int32_t *)ctx->ws[WS_TIES];
-    int32_t n_ties[4] = {0, 0, 0, 0};
-    rc = launch_count_flags(ctx, d_ties, n_reads, d_ties + n_reads);
-    if (rc) return rc;
-    NVK_HIP(hipMemcpyAsync(n_ties, d_ties + n_reads, sizeof n_ties, hipMemcpyDeviceToHost, ctx->stream));
-    NVK_HIP(hipStreamSynchronize(ctx->stream));
-    ctx->last_ties = n_ties[0];
-    ctx->last_ties_exact = n_ties[1];
-    ctx->last_ties_near = n_ties[2];
-    ctx->last_ties_ulp = n_ties[3];
-  }
-  NVK_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->last_ties = tail[0];
+  ctx->last_ties_exact = tail[1];
+  ctx->last_ties_near = tail[2];
+  ctx->last_ties_ulp = tail[3];
   return NVK_OK;
 }
 

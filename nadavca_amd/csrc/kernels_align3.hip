@@ -68,6 +68,7 @@
 #include "nvk_internal.h"
 #include "xmath.h"
 #include "dens.h"
+#include "lane3.h"
 
 namespace {
 
@@ -156,32 +157,6 @@ __device__ __forceinline__ double2 spill_load2(__amdgpu_buffer_rsrc_t rs, int la
     else WAVE_SYNC();               \
   } while (0)
 
-// What one lane needs to sweep one row, per sweep direction: the density of the step it applies
-// (forward: r-1 -> r, reverse: r -> r+1) with ac/mc pre-scaled for density(), its own span and the
-// band of the row it receives from.  Derived from the planner's RowParam table by lane3_kernel so
-// that a lane can fetch its next row (64 rows on) with three 16-byte loads issued one row ahead and
-// held in registers: no row table in LDS, which is what limits the waves per CU.
-struct __attribute__((aligned(16))) Lane3 {
-  double mean, ac, mc;
-  int32_t bs;        // band start of the lane's row
-  int32_t end;       // forward: band end `be`; reverse: span end `hi` (with i + mel <= N folded in)
-  int32_t lo;        // forward: span start (with i - mel >= 0 folded in); reverse: unused
-  int32_t pA, pW;    // the cells at which the lane takes a value from its neighbour, as the one-compare
-                     // test (unsigned)(i - pA) <= pW: the lane is inside its own span AND the predecessor
-                     // cell i -/+ mel lies in the band [pbs, pbe] of the row it receives from, i.e. the
-                     // intersection of [lo, be] (reverse: [bs, hi]) with [pbs + mel, pbe + mel] (reverse:
-                     // - mel).  Everywhere else the lane reads the zero entry of the history ring, which
-                     // also keeps its own value at zero outside its span (it starts a row at zero and
-                     // leaves it at the span's end), so no other masking is needed.  Empty: 2^30, 0.
-  int32_t mg;        // min event length of the applied step | age << 4 | adv << 12: the neighbour's value
-                     // is age = gap + mel >= 1 steps old, gap the time offset between this row and the
-                     // row it receives from (-1 is possible for a row fed by an emitting step); adv (signed)
-                     // the offset between this row and the lane's previous row of the sweep (64 rows
-                     // back) — RowParam::off, kernels_plan.hip
-};
-__device__ __forceinline__ int lane3_pack(int mel, int age, int adv) { return mel | (age << 4) | (adv * 4096); }
-static_assert(sizeof(Lane3) == 48, "Lane3 layout");
-
 struct Align3Args {
   const ReadMeta *metas;
   const Lane3 *fwdl;
@@ -210,68 +185,6 @@ struct Align3Args {
   int32_t *out_events;
   int32_t *out_status;
 };
-
-
-__device__ __forceinline__ void set_density_consts(Lane3 &l, const RowParam &o) {
-  l.mean = o.mean;
-  dens::scale_consts(o.ac, o.mc, l.ac, l.mc);
-  // a row whose density does not depend on the sample (transition rows, kmer_model.cpp:64-94): `mean` is
-  // not used by density() then (mc == 0) and carries the constant itself — what the paired sweeps use
-  // instead of evaluating it (PAIR below)
-  if (l.mc == 0.0) l.mean = dens::constant_density(l.ac);
-}
-
-// one block per read: RowParam rows -> per-sweep lane records
-__global__ __launch_bounds__(256) void lane3_kernel(const ReadMeta *metas, const RowParam *rows,
-                                                    Lane3 *fwdl, Lane3 *revl, int32_t *offs,
-                                                    int n_reads) {
-  const int rd = blockIdx.x;
-  if (rd >= n_reads) return;
-  const ReadMeta m = metas[rd];
-  if (m.status != NVK_READ_OK) return;
-  const RowParam *rw = rows + m.row_off;
-  const int T = m.T, N = m.N, top = T - 1;
-  const int ST = m.cw ? 64 * ALIGN3_TEAM_W : 64;  // rows between a lane's consecutive rows
-  for (int r = threadIdx.x; r < T; r += blockDim.x) {
-    const RowParam o = rw[r];
-    Lane3 f, b;
-    // forward: applies step r-1 -> r
-    f.bs = o.bs; f.end = o.be; f.lo = o.lo;
-    const int adv_f = (r >= ST) ? o.off - rw[r - ST].off : 0;
-    const int adv_b = (r + ST <= top) ? rw[r + ST].off - o.off : 0;
-    if (r > 0) {
-      const RowParam p = rw[r - 1];
-      set_density_consts(f, p);
-      f.lo = max(o.lo, p.mel);
-      {
-        const int a = max(f.lo, p.bs + p.mel), z = min(o.be, p.be + p.mel);
-        f.pA = (z >= a) ? a : 0x40000000; f.pW = (z >= a) ? z - a : 0;
-      }
-      f.mg = lane3_pack(p.mel, o.off - p.off + p.mel, adv_f);
-    } else {
-      f.mean = 1.0; f.ac = 0.0; f.mc = 0.0; f.mg = lane3_pack(0, 1, 0); f.pA = 0x40000000; f.pW = 0;
-    }
-    // reverse: applies step r -> r+1
-    set_density_consts(b, o);
-    b.bs = o.bs; b.lo = 0;
-    if (r < top) {
-      const RowParam q = rw[r + 1];
-      b.end = min(o.hi, N - o.mel);
-      {
-        const int a = max(o.bs, q.bs - o.mel), z = min(b.end, q.be - o.mel);
-        b.pA = (z >= a) ? a : 0x40000000; b.pW = (z >= a) ? z - a : 0;
-      }
-      b.mg = lane3_pack(o.mel, q.off - o.off + o.mel, adv_b);
-    } else {
-      b.pA = 0x40000000; b.pW = 0;
-      b.end = o.hi;
-      b.mg = lane3_pack(o.mel, 1 + o.mel, adv_b);
-    }
-    fwdl[m.row_off + r] = f;
-    revl[m.row_off + r] = b;
-    offs[m.row_off + r] = o.off;
-  }
-}
 
 // (also sets the lane's read index into the history ring: the neighbour's value is D = gap + mel
 // steps old, i.e. in slot (su - D) mod H)
@@ -1198,22 +1111,13 @@ __global__ __launch_bounds__(64 * W, PHASE == 1 ? (W > 1 ? NVK_LB_REV_TEAM : NVK
   }
 }
 
-// steps of the reads in the order they are handed out (two-launch mode: sizes the per-read spill slots)
-__global__ void gather_steps_kernel(const ReadMeta *metas, const int *order, int n, int32_t *out) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p < n) {
-    const ReadMeta m = metas[order[p]];
-    out[p] = (m.status == NVK_READ_OK) ? m.pad : 0;
-  }
-}
-
 }  // namespace
 
 int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadMeta *metas,
-                  const RowParam *rows, const PlanTotals &tot, int32_t *out_events,
-                  int32_t *out_status, int *n_retry) {
+                  const RowParam *rows, const PlanTotals &tot, const int *order, const int32_t *steps_sorted,
+                  int32_t *out_events, int32_t *out_status, int *d_retry) {
   static_assert(WS_OFFS < (int)(sizeof(ctx->ws) / sizeof(ctx->ws[0])), "workspace table too small");
-  *n_retry = 0;
+  (void)rows;  // (the lane records were derived from them by the planner)
   if (a.n_reads == 0) return NVK_OK;
   const int mel = a.mel;
   if (mel < 0 || mel > 4) {
@@ -1221,19 +1125,14 @@ int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadM
     return NVK_ERR_UNSUPPORTED;
   }
   const int max_c = tot.max_c < 1 ? 1 : tot.max_c;
+#if !NVK_TWO_PHASE
   const int max_steps = tot.max_steps < 1 ? 1 : tot.max_steps;
-  const int64_t rows_total = transitions ? 2 * a.total_ref : a.total_ref + a.n_reads;
+#endif
   int rc = nvk_ws_reserve(ctx, WS_MISC, 256);
   if (rc) return rc;
-  rc = nvk_ws_reserve(ctx, WS_LANE_F, (size_t)(rows_total + 1) * sizeof(Lane3));
-  if (rc) return rc;
-  rc = nvk_ws_reserve(ctx, WS_LANE_R, (size_t)(rows_total + 1) * sizeof(Lane3));
-  if (rc) return rc;
-  rc = nvk_ws_reserve(ctx, WS_OFFS, (size_t)(rows_total + 1) * sizeof(int32_t));
-  if (rc) return rc;
   int *counter = (int *)ctx->ws[WS_MISC];
-  int *d_retry = counter + 2;
-  NVK_HIP(hipMemsetAsync(counter, 0, 4 * sizeof(int), ctx->stream));
+  NVK_HIP(hipMemsetAsync(counter, 0, 2 * sizeof(int), ctx->stream));
+  NVK_HIP(hipMemsetAsync(d_retry, 0, sizeof(int), ctx->stream));
 
   // kernels: [0] both sweeps in one wave, [1] reverse sweeps, [2] forward sweeps; rescale period 16
   // compiled in (k16) or taken from the arguments (kv).  With transition rows: the paired variant (one
@@ -1265,17 +1164,6 @@ int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadM
   }
 #undef A3_PICK
 #undef A3_SET
-  {
-    TimerScope ts(ctx, NVK_K_PLAN);
-    hipLaunchKernelGGL(lane3_kernel, dim3((unsigned)a.n_reads), dim3(256), 0, ctx->stream, metas, rows,
-                       (Lane3 *)ctx->ws[WS_LANE_F], (Lane3 *)ctx->ws[WS_LANE_R], (int32_t *)ctx->ws[WS_OFFS],
-                       (int)a.n_reads);
-  }
-  NVK_HIP(hipGetLastError());
-  int *order = nullptr;
-  rc = launch_order(ctx, metas, a.n_reads, max_steps, &order);
-  if (rc) return rc;
-
   // Two launches: the LDS rings are sized by the largest skew a launch serves, so the (usual) reads
   // with c <= ALIGN1_C_CAP keep their 16 waves per CU whatever else is in the batch; wide-band reads
   // (long reads, BASELINE config 5) run with larger rings and a longer rescale period.
@@ -1290,26 +1178,8 @@ int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadM
   if (a.n_reads - n_wide > 0 || max_c <= ALIGN1_C_CAP)
     cls[ncls++] = Cls{0, max_c < ALIGN1_C_CAP ? max_c : ALIGN1_C_CAP, a.n_reads - n_wide, 1};
   if (max_c > ALIGN1_C_CAP) cls[ncls++] = Cls{0, max_cw < C_HARD ? max_cw : C_HARD, n_wide, ALIGN3_TEAM_W};
-#if NVK_TWO_PHASE
-  // steps of the reads in launch order (longest first, bucket by bucket): sizes the per-read spill slots
-  std::vector<int32_t> steps_sorted;
-  try {
-    steps_sorted.resize((size_t)a.n_reads);
-  } catch (const std::bad_alloc &) {
-    nvk_set_error("out of host memory");
-    return NVK_ERR_NOMEM;
-  }
-  rc = nvk_ws_reserve(ctx, WS_STEPS, (size_t)a.n_reads * sizeof(int32_t));
-  if (rc) return rc;
   rc = nvk_ws_reserve(ctx, WS_RSTATE, (size_t)a.n_reads * sizeof(int2));
   if (rc) return rc;
-  hipLaunchKernelGGL(gather_steps_kernel, dim3((unsigned)((a.n_reads + 255) / 256)), dim3(256), 0, ctx->stream,
-                     metas, order, (int)a.n_reads, (int32_t *)ctx->ws[WS_STEPS]);
-  NVK_HIP(hipGetLastError());
-  NVK_HIP(hipMemcpyAsync(steps_sorted.data(), ctx->ws[WS_STEPS], (size_t)a.n_reads * sizeof(int32_t),
-                         hipMemcpyDeviceToHost, ctx->stream));
-  NVK_HIP(hipStreamSynchronize(ctx->stream));
-#endif
   TimerScope ts_align(ctx, NVK_K_ALIGN);
   for (int k = 0; k < ncls; k++) {
     int c = cls[k].hi;
@@ -1348,7 +1218,7 @@ int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadM
     if (per_cu_rev < 1) per_cu_rev = 1;
 #if NVK_TWO_PHASE
     int32_t mxpad = 1;  // the longest read of the batch under the offsets the kernels use (ReadMeta::pad)
-    for (int32_t v : steps_sorted) mxpad = v > mxpad ? v : mxpad;
+    for (int64_t q = 0; q < a.n_reads; q++) mxpad = steps_sorted[q] > mxpad ? steps_sorted[q] : mxpad;
     const int64_t bp_stride = (int64_t)((mxpad + 31) / 32 + 1) * TLk;
 #else
     const int64_t bp_stride = (int64_t)((max_steps + 31) / 32 + 1) * 64;
@@ -1392,7 +1262,7 @@ int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadM
     while (lo < pos_hi) {
       int64_t hi = lo, mx = 1;
       while (hi < pos_hi) {
-        const int64_t m2 = steps_sorted[(size_t)hi] > mx ? steps_sorted[(size_t)hi] : mx;
+        const int64_t m2 = steps_sorted[hi] > mx ? steps_sorted[hi] : mx;
         if (hi > lo && (m2 + 2 * PF) * 512 * W * (hi - lo + 1) > cap) break;
         mx = m2;
         ++hi;
@@ -1405,7 +1275,7 @@ int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadM
         n_chunk = (n_chunk + 1) / 2;
         hi = lo + n_chunk;
         mx = 1;
-        for (int64_t q = lo; q < hi; q++) mx = steps_sorted[(size_t)q] > mx ? steps_sorted[(size_t)q] : mx;
+        for (int64_t q = lo; q < hi; q++) mx = steps_sorted[q] > mx ? steps_sorted[q] : mx;
         spill_stride = (mx + 2 * PF) * 64;
       }
       if (rc) return rc;
@@ -1455,8 +1325,6 @@ int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadM
     NVK_HIP(hipGetLastError());
 #endif
   }
-  NVK_HIP(hipMemcpyAsync(n_retry, d_retry, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-  NVK_HIP(hipStreamSynchronize(ctx->stream));
   // bytes the sweeps stream through HBM: 8 B written + 8 B read per (step, lane) + scales + bits
   ctx->last_spill_bytes = (int64_t)tot.steps * 64 * 16 + (int64_t)tot.steps / 16 * 8 + (int64_t)tot.steps * 8 * 2;
   return NVK_OK;

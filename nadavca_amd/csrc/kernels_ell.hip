@@ -865,7 +865,8 @@ int launch_ell(nvk_ctx *ctx, const DeviceModel &dm, const BatchArgs &a, int wobb
   g.counter = counter;
   {
     int *order = nullptr;
-    rc = launch_order(ctx, pl.metas, a.n_reads, tot.max_steps, &order);
+    // (the planner's totals are still where launch_plan_ell left them: ws[WS_MISC] + 64, api.hip)
+    rc = launch_order(ctx, pl.metas, a.n_reads, (const PlanTotals *)((const char *)ctx->ws[WS_MISC] + 64), &order, nullptr);
     if (rc) return rc;
     g.order = order;
   }

@@ -10,6 +10,7 @@
 #include <math.h>
 
 #include "nvk_internal.h"
+#include "lane3.h"
 
 namespace {
 
@@ -154,7 +155,8 @@ constexpr int PLAN_T = 256;
 __global__ __launch_bounds__(PLAN_T) void plan_kernel(DeviceModel dm, BatchArgs a, int mode,
                                                   double log_p_in, int c_cap, ReadMeta *metas,
                                                   RowParam *rows, unsigned long long *bandtmp,
-                                                  PlanTotals *totals) {
+                                                  PlanTotals *totals, Lane3 *lane_f, Lane3 *lane_r,
+                                                  int32_t *lane_offs) {
   const int rd = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63;
   __shared__ unsigned long long sh_cells;
@@ -419,6 +421,12 @@ __global__ __launch_bounds__(PLAN_T) void plan_kernel(DeviceModel dm, BatchArgs 
   const int cu = team ? cw : c;  // uniform offsets
   for (int r = tid; r < T; r += PLAN_T) rp[r].off = var_ok ? sh_x[r] - x0 + sh_S[r] : cu * r;
   const int off_top = var_ok ? sh_x[T - 1] - x0 + sh_S[T - 1] : cu * (T - 1);
+  // the per-sweep lane records of kernels_align3.hip, while the read's rows are still in this CU's caches
+  // (lane3.h; a kernel of its own used to re-read the whole row table for them)
+  if (lane_f && !badband) {
+    __syncthreads();  // every row's offset is written
+    lane3_rows(rp, T, N, cw, lane_f + m.row_off, lane_r + m.row_off, lane_offs + m.row_off, tid, PLAN_T);
+  }
 
   if (tid == 0) {
     int t_min = rp[0].lo;
@@ -634,9 +642,11 @@ __device__ __forceinline__ int order_bucket(const ReadMeta &m, int max_steps) {
   const int sb = ORD_B - 1 - (int)(b < 0 ? 0 : (b > ORD_B - 1 ? ORD_B - 1 : b));
   return (m.cw != 0 ? 0 : ORD_B) + sb;
 }
-__global__ void order_count_kernel(const ReadMeta *metas, int n, int max_steps, int *cnt) {
+// (max_steps comes from the planner's totals ON THE DEVICE: the order is built behind the planner without a host
+// round trip in between)
+__global__ void order_count_kernel(const ReadMeta *metas, int n, const PlanTotals *tot, int *cnt) {
   int rd = blockIdx.x * blockDim.x + threadIdx.x;
-  if (rd < n) atomicAdd(&cnt[order_bucket(metas[rd], max_steps)], 1);
+  if (rd < n) atomicAdd(&cnt[order_bucket(metas[rd], tot->max_steps)], 1);
 }
 __global__ void order_scan_kernel(int *cnt) {  // one wave, two buckets per lane: cnt[b] -> first position of bucket b; cnt[ORD_N+b] = 0
   int lane = threadIdx.x;
@@ -650,11 +660,20 @@ __global__ void order_scan_kernel(int *cnt) {  // one wave, two buckets per lane
   cnt[ORD_N + 2 * lane] = 0;
   cnt[ORD_N + 2 * lane + 1] = 0;
 }
-__global__ void order_fill_kernel(const ReadMeta *metas, int n, int max_steps, int *cnt, int *order) {
+__global__ void order_fill_kernel(const ReadMeta *metas, int n, const PlanTotals *tot, int *cnt, int *order) {
   int rd = blockIdx.x * blockDim.x + threadIdx.x;
   if (rd < n) {
-    int b = order_bucket(metas[rd], max_steps);
+    int b = order_bucket(metas[rd], tot->max_steps);
     order[cnt[b] + atomicAdd(&cnt[ORD_N + b], 1)] = rd;
+  }
+}
+
+// steps of the reads in the order they are handed out (sizes the per-read spill slots of kernels_align3.hip)
+__global__ void gather_steps_kernel(const ReadMeta *metas, const int *order, int n, int32_t *out) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n) {
+    const ReadMeta m = metas[order[p]];
+    out[p] = (m.status == NVK_READ_OK) ? m.pad : 0;
   }
 }
 
@@ -689,7 +708,8 @@ int launch_count_flags(nvk_ctx *ctx, const int32_t *flags, int64_t n, int32_t *o
 }
 
 // order[0..n) = read indices, longest (by step count) first; `order` lives in ctx->ws[WS_ORDER]
-int launch_order(nvk_ctx *ctx, const ReadMeta *metas, int64_t n_reads, int max_steps, int **order) {
+int launch_order(nvk_ctx *ctx, const ReadMeta *metas, int64_t n_reads, const PlanTotals *tot_dev, int **order,
+                 int32_t *steps_out) {
   *order = nullptr;
   if (n_reads <= 0) return NVK_OK;
   int rc = nvk_ws_reserve(ctx, WS_ORDER, (size_t)n_reads * sizeof(int) + 2 * ORD_N * sizeof(int));
@@ -699,16 +719,19 @@ int launch_order(nvk_ctx *ctx, const ReadMeta *metas, int64_t n_reads, int max_s
   NVK_HIP(hipMemsetAsync(cnt, 0, 2 * ORD_N * sizeof(int), ctx->stream));
   const unsigned blocks = (unsigned)((n_reads + 255) / 256);
   TimerScope ts(ctx, NVK_K_PLAN);
-  hipLaunchKernelGGL(order_count_kernel, dim3(blocks), dim3(256), 0, ctx->stream, metas, (int)n_reads, max_steps, cnt);
+  hipLaunchKernelGGL(order_count_kernel, dim3(blocks), dim3(256), 0, ctx->stream, metas, (int)n_reads, tot_dev, cnt);
   hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(64), 0, ctx->stream, cnt);
-  hipLaunchKernelGGL(order_fill_kernel, dim3(blocks), dim3(256), 0, ctx->stream, metas, (int)n_reads, max_steps, cnt, ord);
+  hipLaunchKernelGGL(order_fill_kernel, dim3(blocks), dim3(256), 0, ctx->stream, metas, (int)n_reads, tot_dev, cnt, ord);
+  if (steps_out)
+    hipLaunchKernelGGL(gather_steps_kernel, dim3(blocks), dim3(256), 0, ctx->stream, metas, ord, (int)n_reads, steps_out);
   NVK_HIP(hipGetLastError());
   *order = ord;
   return NVK_OK;
 }
 
 int launch_plan(nvk_ctx *ctx, const DeviceModel &dm, const BatchArgs &a, int mode, int wobbling,
-                ReadMeta *metas, RowParam *rows, unsigned long long *bandtmp, PlanTotals *totals) {
+                ReadMeta *metas, RowParam *rows, unsigned long long *bandtmp, PlanTotals *totals,
+                void *lane_f, void *lane_r, int32_t *lane_offs) {
   (void)wobbling;
   NVK_HIP(hipMemsetAsync(totals, 0, sizeof(PlanTotals), ctx->stream));
   if (a.n_reads == 0) return NVK_OK;
@@ -717,7 +740,8 @@ int launch_plan(nvk_ctx *ctx, const DeviceModel &dm, const BatchArgs &a, int mod
     // the transition constant comes from the host libm, like the model's ac/mc (kmer_model.cpp:77)
     const double log_p_in = log(0.01);
     hipLaunchKernelGGL(plan_kernel, dim3((unsigned)a.n_reads), dim3(PLAN_T), 0, ctx->stream, dm, a, mode,
-                       log_p_in, ALIGN1_C_CAP, metas, rows, bandtmp, totals);
+                       log_p_in, ALIGN1_C_CAP, metas, rows, bandtmp, totals, (Lane3 *)lane_f, (Lane3 *)lane_r,
+                       lane_offs);
   }
   NVK_HIP(hipGetLastError());
   return NVK_OK;

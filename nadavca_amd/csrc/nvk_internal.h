@@ -97,6 +97,10 @@ struct nvk_ctx {
   int64_t last_ties_exact, last_ties_near, last_ties_ulp;  // ... per class (NVK_TIE_EXACT / _NEAR / _ULP)
   int64_t ties_n;        // number of reads ws[WS_TIES] describes
   int64_t ws_limit;      // nvk_ctx_set_workspace_limit: cap on the sweep kernels' spill workspace (0 = default)
+  // one pinned host block the planner's results arrive in with ONE copy + synchronisation per batch: the totals,
+  // then the reads' step counts in launch order (refine_alignment; sizes the spill slots)
+  void *h_plan;
+  size_t h_plan_cap;
   int spill_share;       // > 1: this ctx is one of that many lanes of a pipelined host path sharing the device
   struct nvk_pipe_state *pipe;  // lanes of the pipelined host-pointer entry points (pipeline.hip), made on first use
 };
@@ -151,9 +155,15 @@ struct BatchArgs {
 
 enum { PLAN_ALIGN_TRANS = 0, PLAN_ALIGN_PLAIN = 1, PLAN_ELL = 2 };
 
+// lane_f / lane_r / lane_offs: where the planner leaves the per-sweep lane records of kernels_align3.hip (lane3.h),
+// or null
 int launch_plan(nvk_ctx *ctx, const DeviceModel &dm, const BatchArgs &a, int mode, int wobbling,
-                ReadMeta *metas, RowParam *rows, unsigned long long *bandtmp, PlanTotals *totals);
-int launch_order(nvk_ctx *ctx, const ReadMeta *metas, int64_t n_reads, int max_steps, int **order);
+                ReadMeta *metas, RowParam *rows, unsigned long long *bandtmp, PlanTotals *totals,
+                void *lane_f, void *lane_r, int32_t *lane_offs);
+// order[0..n) = read indices in launch order (class-major, longest first; ctx->ws[WS_ORDER]); tot_dev: the planner's
+// totals on the device; steps_out (device, n ints, or null): the reads' step counts in that order
+int launch_order(nvk_ctx *ctx, const ReadMeta *metas, int64_t n_reads, const PlanTotals *tot_dev, int **order,
+                 int32_t *steps_out);
 int launch_align(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadMeta *metas,
                  const RowParam *rows, const PlanTotals &tot, int32_t *out_events,
                  int32_t *out_status);
@@ -180,10 +190,12 @@ constexpr int ALIGN1_C_CAP = 3;  // skew served by the main launch of the one-re
 int launch_align_retry(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadMeta *metas,
                        const RowParam *rows, const PlanTotals &tot, int32_t *out_events,
                        int32_t *out_status);
-// scaled-double kernel (kernels_align3.hip); *n_retry = reads it handed to the exact kernel
+// scaled-double kernel (kernels_align3.hip).  order / steps_sorted: launch order (device) and the reads' step counts
+// in that order (host), both from plan_batch; d_retry (device int, zeroed here): reads it hands to the exact kernel.
+// Asynchronous: nothing is waited for.
 int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadMeta *metas,
-                  const RowParam *rows, const PlanTotals &tot, int32_t *out_events,
-                  int32_t *out_status, int *n_retry);
+                  const RowParam *rows, const PlanTotals &tot, const int *order, const int32_t *steps_sorted,
+                  int32_t *out_events, int32_t *out_status, int *d_retry);
 int launch_expected(nvk_ctx *ctx, const DeviceModel &dm, int64_t n_reads, int64_t total_ref,
                     const int32_t *reference, const int64_t *ref_off, const int32_t *cb,
                     const int64_t *cb_off, const int32_t *ca, const int64_t *ca_off, double *out);

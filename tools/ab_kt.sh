@@ -5,7 +5,7 @@ LOG=$1; shift
 export TMPDIR=/tmp
 for v in "$@"; do
   rm -rf gpurun_out/_kt
-  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/_kt -o kt -- python3 tools/bench_variant.py variants/lib_$v.so --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> gpurun_out/_kt.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/_kt -o kt -- python3 tools/bench_variant.py variants/lib_$v.so --steps 3 --warmup 1 --no-cpu-baseline --no-e2e > /dev/null 2> gpurun_out/_kt.err
   echo "== $v" >> $LOG
   find gpurun_out/_kt -name "*kernel_stats.csv" | head -1 | xargs grep align3 | python3 -c "
 import sys,csv

@@ -11,7 +11,7 @@ for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "SQ_INST_LEVEL_LDS SQ_INST_LEVEL_SMEM SQ_INST_LEVEL_VMEM SQ_IFETCH SQ_IFETCH_LEVEL SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
            "SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_LDS_ADDR_CONFLICT SQ_LDS_CMD_FIFO_FULL SQ_LDS_DATA_FIFO_FULL SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_VMEM_WR_TA_DATA_FIFO_FULL"; do
   i=$((i+1))
-  rocprofv3 --pmc $SET --output-format csv -d $OUT/${TAG}_pmc$i -o pmc -- python3 tools/bench_variant.py $LIB --steps 1 --warmup 0 --no-cpu-baseline > $OUT/${TAG}_pmc$i.json 2> $OUT/${TAG}_pmc$i.err
+  rocprofv3 --pmc $SET --output-format csv -d $OUT/${TAG}_pmc$i -o pmc -- python3 tools/bench_variant.py $LIB --steps 1 --warmup 0 --no-cpu-baseline --no-e2e > $OUT/${TAG}_pmc$i.json 2> $OUT/${TAG}_pmc$i.err
   echo "pass $i done"
 done
 python3 - $OUT $TAG <<'PY' > $OUT/${TAG}_pmc.txt
