@@ -206,7 +206,9 @@ def main():
             def step():
                 chunks = estimate_snps_batch(genome, rb, config=cfg_snps, kmer_model=km, aligner=aligner,
                                              fit_workers=args.fit_workers)
-                extra['reads_ok'] = n_reads
+                from nadavca_amd.estimate_snps import last_batch_counts
+                extra['reads_ok'] = last_batch_counts.get('reads_ok')       # status 0 after the log-likelihoods
+                extra['reads_fitted'] = last_batch_counts.get('reads_fitted')
                 extra['chunks'] = len(chunks)
         stats_of = lambda: ctx.last_batch_stats()
     else:
@@ -309,7 +311,7 @@ def main():
                         'wave_steps_per_read': round(stats['wave_steps'] / n_reads, 1)})
         if wname == 'api_estimate_snps':
             cfg.update({'tweak_signal_normalization': not args.no_tweak, 'fit_workers': args.fit_workers,
-                        'chunk_groups': extra.get('chunks')})
+                        'chunk_groups': extra.get('chunks'), 'reads_spline_fitted': extra.get('reads_fitted')})
         if is_align or wname == 'api_align_signal':
             cfg.update({'reads_redone_exact': stats['reads_redone_exact'],
                         # reads in which a path comparison fell inside the tie margin (include/nadavca_hip.h):
@@ -353,7 +355,7 @@ def main():
             insts, src = profile_figure('cfg3_snps', 'valu_insts_per_read')
             traffic, _ = profile_figure('cfg3_snps', 'hbm_bytes_per_read')
             algo = dbatch.algorithmic_bytes_snp(stats['band_cells'])
-            rl = {'bound': 'valu', 'kernel': kname, 'unit': 'TFLOP/s', 'peak': VALU_PEAK_TLANE,
+            rl = {'bound': 'valu', 'kernel': kname, 'unit': 'Tlane-inst/s', 'peak': VALU_PEAK_TLANE,
                   'note': 'vector lane-instructions per second, in units of 1e12 (an FMA counts once, so these '
                           'are not flops); peak = 1 wave64 instruction / 4 cycles / SIMD at 2.4 GHz x 1024 SIMDs '
                           'x 64 lanes', 'from_profile': src,
@@ -363,6 +365,16 @@ def main():
             if insts:
                 rl['achieved'] = insts * n_reads * 64 / sec / 1e12
                 rl['frac'] = rl['achieved'] / VALU_PEAK_TLANE
+                # `frac` is pipe utilisation: any wasted instruction raises it.  Work efficiency: executed
+                # lane-instructions per row-cell update (4 R sweep rows + 3 R (2 k + 1) hypothesis rows,
+                # each as wide as its band) against what the recurrences need (one table density
+                # per two row-cells, a mixture + multiply-add on a wobble row, an emission product + two
+                # multiply-adds on an emitting row, each value a (mantissa, exponent) pair: ~21)
+                rows_per_base = 4 + 3 * (2 * model[0] + 1)
+                per_cell = insts * 64.0 / (rows_per_base * stats['band_cells'] / n_reads)
+                rl['lane_insts_per_row_cell_update'] = per_cell
+                rl['floor_lane_insts_per_row_cell_update'] = 21.0
+                rl['work_efficiency'] = rl['frac'] * 21.0 / per_cell
             else:
                 rl['achieved'] = rl['frac'] = None
             out['roofline'] = rl

@@ -75,6 +75,11 @@ def _check_status(what, status, live):
                      % (what, int(wide.sum()), live[torch.nonzero(wide).reshape(-1)[:8]].tolist()))
 
 
+# what the last estimate_snps_batch call saw (bench.py reports it): reads in the batch, reads with an approximate
+# alignment, reads whose log-likelihoods came back with status 0, reads the spline tweak fitted
+last_batch_counts = {}
+
+
 class IndependentChunks:
     """``estimate_snps(independent=True)`` for a batch: one chunk per read that produced one, as arrays —
     read ``reads[j]`` covers reference positions [start[j], end[j]) and has posterior rows
@@ -151,6 +156,8 @@ def estimate_snps_batch(reference_num, read_batch, config=defaults.CONFIG_FILE,
     sa = readbatch.signal_alignments(rb, ba, bw, reference_num, kmer_model.get_k(),
                                      kmer_model.get_central_position(), device=device)
     n_live = int(sa.live.numel())
+    last_batch_counts.clear()
+    last_batch_counts.update(reads=int(rb.n), reads_aligned=n_live, reads_ok=0, reads_fitted=None)
     if n_live == 0:
         if independent:
             return IndependentChunks(numpy.zeros(0, dtype=numpy.int64), *[numpy.zeros(0)] * 3,
@@ -171,6 +178,7 @@ def estimate_snps_batch(reference_num, read_batch, config=defaults.CONFIG_FILE,
         ref_off_h = sa.ref_off.cpu().numpy()
         t, c, knot_off, fitted = splinefit.fit_splines(means.cpu().numpy(), expected.cpu().numpy(), ref_off_h,
                                                        st0.cpu().numpy() == 0, workers=fit_workers)
+        last_batch_counts['reads_fitted'] = int(fitted.sum())
         # reads without a fit keep their signal (the reference would fail on them): a placeholder spline for
         # the kernel, the original samples restored afterwards
         ident_t = numpy.array([-5.0] * 4 + [5.0] * 4)
@@ -198,6 +206,7 @@ def estimate_snps_batch(reference_num, read_batch, config=defaults.CONFIG_FILE,
     k, prior = kmer_model.get_k(), config['snp_prior_probability']
     ref_dev = torch.from_numpy(reference_num).to(device)
     ok = (status == 0)
+    last_batch_counts['reads_ok'] = int(ok.sum())
     if independent:
         # every read a segment of its own, laid end to end (estimate_snps.py:63-68)
         acc, _ = consensus_accumulate_dev(context, dbatch, ll, sa.ref_off[:-1].contiguous(), rev32, status, nel,
