@@ -23,11 +23,11 @@
 //   that mattered shows up as a row whose sum deviates.  A flagged read is re-run by the exact
 //   kernel (status NVK_READ_RETRY_INTERNAL, never visible to callers).
 //
-//   Path DP: the scores one wave holds at one step belong to 64 consecutive rows (a team: 256) — a few
-//   hundred bits apart on the path — so they, too, are plain doubles, under a second wave-uniform running
-//   scale moved at the same steps as the first; the tie margin of xm::gt_tol (|exponent| * 2^-52) takes its
-//   exponent from the wave's largest score of the last rescale step.  (Round 2 kept (double, integer scale)
-//   pairs per score: a second LDS word per slot, an ldexp per comparison and a frexp chain per update.)
+//   Path DP: scores of one row only ever meet scores of the same row (running maximum, arg-max)
+//   or are handed to the next row, so scores are (double, integer scale) pairs: the running maximum
+//   is kept normalised (mantissa in [0.5,1), scale G), an incoming score is shifted onto that scale
+//   before the comparison, and G travels with the score — which is all the tie tolerance of
+//   xm::gt_tol needs.
 //
 // Memory: spill 8 B per cell (+4 B of scale per RS steps) instead of 12 B per cell; no row table in LDS
 // (lane3_kernel prepares per-sweep lane records, a lane fetches the record of its next row through the scalar
@@ -98,6 +98,7 @@ static_assert(FT % PF == 0 && 32 % FT == 0, "forward trip");
 static_assert(32 % PF == 0 && PF % 2 == 0 && 32 % RU == 0 && RU % 2 == 0, "the step count is a multiple of 32 (kernels_plan.hip)");
 // rescale period: 2^rsh steps (launch parameter, >= 16); must exceed c + mel so that at most one
 // rescale lies inside the window a neighbour value travels through
+constexpr int GBIG = 1 << 24;  // scale of an empty running maximum (see the path step)
 // Largest upward move per rescale.  When the wave's largest value collapses by more than this within one
 // period (only off-path cells live, or a sharp model on a noisy signal) the running scale cannot follow
 // without sending the next densities' exponents out of range; the move is capped (no inf / NaN is ever
@@ -108,10 +109,6 @@ constexpr int DMAX = 1000;  // the density exponent (<= ~3) plus the move must s
                             // (1000: a long read's reverse sweep ends in far-off-path cells that collapse by
                             // ~28 bits per step — 906 bits in a 32-step period on BASELINE config 5 reads)
 constexpr int TARGET = 250; // exponent the largest live value is moved to
-constexpr int PTARGET = -150;  // path scores (forward sweep): exponent the largest running maximum is moved to ...
-constexpr int PSTEP = 900;     // ... unless it lies more than this far below it (only junk live: the scale stays).
-                               // PTARGET + PSTEP + 136 < 1000: what a junk-sized move can lift a real score to;
-                               // PTARGET - 768 > -1022: room below the largest for the rows a team holds
 #define HUGE_V 0x1.0p+900
 #define MASS_TOL 1e-9          // allowed relative spread of the rows' posterior mass
 #ifndef NVK_TIE_BITS
@@ -305,11 +302,10 @@ __global__ __launch_bounds__(64 * W, PHASE == 1 ? (W > 1 ? NVK_LB_REV_TEAM : NVK
   // predecessor's band reads it instead of masking what it read (one select on the index instead of
   // one per loaded register)
   // (the reverse-only launch keeps 8 bytes per lane and slot: its zero entry is hist[H*64])
-  int *s_read = (PHASE == 1) ? reinterpret_cast<int *>(hist + (size_t)g.H * TL + 1)
-                             : reinterpret_cast<int *>(hist2 + (size_t)g.H * TL + 1);
-  // team exchange: every wave's largest exponent (rescale; tmax2: of its path scores), its flags, and the last
-  // row's arg-max
-  int *tmax = s_read + 2, *tflag = tmax + W, *tfidx = tflag + W, *tmax2 = tfidx + 1;
+  int *ghist = reinterpret_cast<int *>(hist2 + (size_t)g.H * TL + 1);
+  int *s_read = (PHASE == 1) ? reinterpret_cast<int *>(hist + (size_t)g.H * TL + 1) : ghist + (size_t)g.H * TL + 1;
+  // team exchange: every wave's largest exponent (rescale), its flags, and the last row's arg-max
+  int *tmax = s_read + 2, *tflag = tmax + W, *tfidx = tflag + W;
 
   const int lane = gl & 63;
   const int H = g.H, RM = g.SR - 1;
@@ -323,12 +319,14 @@ __global__ __launch_bounds__(64 * W, PHASE == 1 ? (W > 1 ? NVK_LB_REV_TEAM : NVK
       hist[HZ] = 0.0;
     } else {
       hist2[HZ] = make_double2(0.0, 0.0);
+      ghist[HZ] = 0;
     }
   }
   // per-lane constants kept in vector registers (the compiler would otherwise rebuild them from scalars
   // with one or two VOP3 instructions at every use): byte offsets of the lane inside a history slot and
   // the indices of the zero entry
   unsigned char *histb = reinterpret_cast<unsigned char *>(hist2);
+  unsigned char *ghistb = reinterpret_cast<unsigned char *>(ghist);
   int gl16 = gl * 16, gl8 = gl * 8, HZv = HZ, HZ2v = (PHASE == 1) ? HZ : 2 * HZ;
   asm volatile("" : "+v"(gl16), "+v"(gl8), "+v"(HZv), "+v"(HZ2v));
   const int lane16 = (W == 1) ? gl16 : lane * 16;  // the lane's offset inside a step of the wave's spill
@@ -680,43 +678,11 @@ __global__ __launch_bounds__(64 * W, PHASE == 1 ? (W > 1 ? NVK_LB_REV_TEAM : NVK
     __syncthreads();  // (also drains the stores)
     __builtin_amdgcn_s_dcache_inv();
 
-    // The posterior's normalisation.  post[r][i] = prefix * suffix * 2^-Kt with Kt the exponent of the TOTAL
-    // sum_i suffix[0][i] over row 0's band (prefix[0] is all ones): every row's posterior mass is then in [0.5, 1)
-    // and a row multiplies the path scores by the posterior of its boundary — at most a few bits.  (A constant
-    // factor per row never changes a decision — scores only meet scores of their own row — and round 2, which kept
-    // an exponent per score, normalised by K, the largest suffix value lane 0 met on row 0 INCLUDING its pre-roll
-    // cells above the band: masses of 2^-18 per row on config-2 reads, 2^-14000 over a read.  The wave-uniform
-    // path scale below wants the 64 rows a wave holds within a few hundred bits.)  Row 0's cells are read back
-    // from the spill: cell i was written at forward step i - t_min by lane 0 (wave 0 of a team).
-    int Kt = 0;
-    {
-      const Lane3 r0 = fwdl[0];
-      const int b0 = __builtin_amdgcn_readfirstlane(r0.bs), e0 = __builtin_amdgcn_readfirstlane(r0.end);
-      const double *sp0 = g.spill_v + slot * W * g.spill_stride;
-      int emax = -0x40000000;
-      for (int ci = b0 + lane; ci <= e0; ci += 64) {
-        const int uf = ci - t_min;  // (offs[0] == 0)
-        const double v = sp0[(size_t)(uf >> 1) * 128 + (uf & 1)];
-        if (v != 0.0) emax = max(emax, __builtin_amdgcn_frexp_exp(v) - spill_L[(n_steps - 1 - uf) >> RSH]);
-      }
-      emax = wave_max_i(emax);
-      if (emax > -0x40000000) {
-        double ssum = 0.0;
-        for (int ci = b0 + lane; ci <= e0; ci += 64) {
-          const int uf = ci - t_min;
-          const double v = sp0[(size_t)(uf >> 1) * 128 + (uf & 1)];
-          ssum += ldexp(v, -spill_L[(n_steps - 1 - uf) >> RSH] - emax);
-        }
-        for (int dlt = 32; dlt >= 1; dlt >>= 1) ssum += __shfl_xor(ssum, dlt, 64);
-        Kt = __builtin_amdgcn_readfirstlane(emax + __builtin_amdgcn_frexp_exp(ssum));
-      }
-    }
-
     // ================= forward sweep: prefix rows, posterior, path DP, update bits =================
     // arg-max of the last row: best score, its margin, its scale, its cell (in registers: kept in LDS, read
     // and written by the last row's lane only, it cost 4 % — one more LDS round trip on that row's steps)
-    double fbest = 0.0;
-    int fidx = -1;
+    double fbest = 0.0, fthr = 0.0;
+    int fidx = -1, fG = 0;
     // (scalar) lanes that saw a comparison inside the tie margin, by class (include/nadavca_hip.h): the two scores
     // exactly equal (amb_x), different but within NVK_TIE_ULPS margins of xm::gt_tol — ulps of the reference's
     // log value, where its own rounding may decide — (amb_u), beyond that but inside 2^-24 relative (amb_n)
@@ -748,17 +714,8 @@ __global__ __launch_bounds__(64 * W, PHASE == 1 ? (W > 1 ? NVK_LB_REV_TEAM : NVK
       double prev = 0.0, e1 = 1.0, e2 = 1.0, e3 = 1.0;
       // path DP state of the row: running maximum of the previous row's scores (raw, as received,
       // and normalised by 2^rho), its tolerance margin, the row's accumulated exponent G
-      double bestn = 0.0;
-      // Path scores are plain doubles under a second wave-uniform running scale (ps, moved at the same steps as the
-      // prefix scale): score_stored = score_true * 2^ps.L.  The scores one wave holds at one step belong to at most
-      // 64 (a team: 256) consecutive rows — a couple of hundred bits apart on the path — so one scale serves them
-      // as it serves the prefix values, and the (double, int scale) pairs, their ldexp / frexp chains and the
-      // second LDS word per slot are gone.  cE: the tie margin of xm::gt_tol, |exponent| * 2^-52, taken from the
-      // wave's largest true exponent at the last rescale step (scalar; the scores of one step differ from it by a
-      // few per cent of |exponent| at most, and the margin only has to tell rounding-level ties from real
-      // differences).
-      Scale ps{0, 0, 0};
-      double cE = 0.0;
+      double bestn = 0.0, bthr = 0.0;
+      int G = GBIG;  // scale of bestn, and so of this row's scores
       // Flush detector.  In a banded forward-backward pass every allowed path crosses every row
       // exactly once, so sum_i prefix[r][i] * suffix[r][i] is the SAME total for every row r.
       // Cells far below the wave's scale flush to zero here; if that ever removes mass that
@@ -820,17 +777,9 @@ __global__ __launch_bounds__(64 * W, PHASE == 1 ? (W > 1 ? NVK_LB_REV_TEAM : NVK
             if (age == 0 && u > 0) {
               sc.L += sc.d_next;
               sc.d_last = sc.d_next;
-              ps.L += ps.d_next;
-              ps.d_last = ps.d_next;
-              sh_until = ((sc.d_next | ps.d_next) != 0) ? u + c + MEL : 0;
+              sh_until = (sc.d_next != 0) ? u + c + MEL : 0;
               sc.d_next = 0;
-              ps.d_next = 0;
               if (PAIR) { cq = ldexp(cq, sc.d_last); dsel = 0; }
-              if (ps.d_last != 0) {  // (rare, uniform) the lane's running maxima move with the path scale
-                asm volatile("");
-                bestn = ldexp(bestn, ps.d_last);
-                fbest = ldexp(fbest, ps.d_last);
-              }
             }
             if (PAIR && age == 1 && u > 1) cq = ldexp(cq, -sc.d_last);
             shift_now = (age == 0 && u > 0) ? sc.d_last : 0;
@@ -850,7 +799,7 @@ __global__ __launch_bounds__(64 * W, PHASE == 1 ? (W > 1 ? NVK_LB_REV_TEAM : NVK
                   r = rn;
                   i -= nx.mg >> 12;
                   prev = 0.0;
-                  bestn = 0.0;
+                  bestn = 0.0; bthr = 0.0; G = GBIG;
                   if (r < T) {
                     TAKE_LANE(nx);
                     be = nx.end; lo = nx.lo;
@@ -918,8 +867,10 @@ __global__ __launch_bounds__(64 * W, PHASE == 1 ? (W > 1 ? NVK_LB_REV_TEAM : NVK
 #endif
 #if NVK_ABL == 3
             const double2 hv = make_double2(prev * 0.5, bestn);
+            const int Gin = G;
 #else
             const double2 hv = hist2[hs];
+            const int Gin = ghist[hs];
 #endif
             const bool sh_any = (u < sh_until);
             DensHalf dn;
@@ -930,13 +881,11 @@ __global__ __launch_bounds__(64 * W, PHASE == 1 ? (W > 1 ? NVK_LB_REV_TEAM : NVK
 #define IN_BAND ((i >= lo) && (i <= be) && (i >= bs))
             double P = emission_product<MEL>(e, e1, e2, e3);
             if (MEL > 0) P = fma(P, pm, qm);
-            const double pv = hv.x;
-            double dv = hv.y;
+            const double pv = hv.x, dv = hv.y;
             double t1 = P * pv;
-            if (sh_any) {  // see the reverse sweep; the neighbour's path score missed the path scale's move likewise
+            if (sh_any) {  // see the reverse sweep
               asm volatile("");
               t1 = ldexp(t1, ((age < D) ? sc.d_last : 0) - ((age < melr) ? sc.d_last : 0));
-              dv = ldexp(dv, (age < D) ? ps.d_last : 0);
             }
             const double ee = PAIR ? fma(e, pm, cq) : e;
             double o = fma(ee, prev, t1);
@@ -946,71 +895,86 @@ __global__ __launch_bounds__(64 * W, PHASE == 1 ? (W > 1 ? NVK_LB_REV_TEAM : NVK
             const int ur = n_steps - 1 - u;  // the reverse sweep's step for this anti-diagonal
             // (a compiled-in period divides n_steps: the reverse sweep's rescale steps are this sweep's age-0 steps)
             if (RSHC ? (age == 0) : ((ur & (RS - 1)) == RS - 1 || u == 0)) Lrev = sL[ur >> RSH];
-            const int kap = -(sc.L + Kt) - Lrev;  // scalar
+            const int kap = -(sc.L + K) - Lrev;  // scalar
             // No band test here: a cell of the lane's warm-up (lo <= i < bs) has suf == 0, because the
             // reverse sweep's lane was idle at this (step, lane) — it leaves row r at bs and the planner
             // keeps its next row (r - 64) from reaching back into [lo, be] of row r — and beyond `be`
             // o is 0.  (A violation would show up in the row-mass check.)
             double post = ldexp(o * suf, kap);
             // ---- path step (node.cpp:52-91): running maximum of the previous row, strict '>' at the
-            // resolution of the reference's log-doubles (xm::gt_tol): margin = best * |exponent| * 2^-52, the
-            // exponent taken per wave and rescale period (cE above).  Both scores are on the wave's path scale
-            // (a score far below the running maximum is simply smaller, one that underflows the scale is an exact
-            // zero: compiled with FP64 denormals flushed).
-            const double tdiff = dv - bestn;
-            const double thr = bestn * cE;
-            const bool upd = (tdiff > thr);  // (dv == 0 outside the span: never an update)
-            // The tie flags (include/nadavca_hip.h, parity contract): the two scores are closer than 2^-24
+            // resolution of the reference's log-doubles (xm::gt_tol): margin = best * |exponent| * 2^-52
+            // Scores are (double, integer scale): stored = true * 2^scale.  The running maximum is kept
+            // normalised (bestn in [0.5,1), scale G); an incoming score is brought onto that scale
+            // before comparing (far below -> 0, far above -> inf, both compare correctly).
+#if NVK_ABL == 5
+            const double dva = dv;
+#else
+            const double dva = ldexp(dv, G - Gin);  // no maximum yet: G = GBIG, any dv > 0 becomes +inf
+#endif
+            const double tdiff = dva - bestn;
+            const bool upd = (tdiff > bthr);  // (dv == 0 outside the span: never an update)
+            // The tie flag (include/nadavca_hip.h, parity contract): the two scores are closer than 2^-24
             // relative — far more than the rounding either this engine or the reference accumulates, so a
-            // read without a flag has the reference's decisions everywhere.  (A candidate of 0 never qualifies.)
+            // read without the flag has the reference's decisions everywhere.  (A candidate of 0, or the
+            // +inf a first candidate turns into, never qualifies.  Scores of cells thousands of bits below
+            // the path would tie by their lost precision: this file is compiled with FP64 denormals
+            // flushed, which makes them exact zeros.)
 #if !NVK_NO_TIEFLAG
             {
-              const unsigned long long nr = __builtin_amdgcn_ballot_w64(fabs(tdiff) < dv * TIE_FLAG_REL);
+              const unsigned long long nr = __builtin_amdgcn_ballot_w64(fabs(tdiff) < dva * TIE_FLAG_REL);
               if (nr != 0) {  // (rare, a scalar branch: the classes are sorted out off the usual path)
                 asm volatile("");
                 const unsigned long long zr = __builtin_amdgcn_ballot_w64(tdiff == 0.0);
-                const unsigned long long ur = __builtin_amdgcn_ballot_w64(fabs(tdiff) <= thr * (double)NVK_TIE_ULPS);
+                const unsigned long long ur = __builtin_amdgcn_ballot_w64(fabs(tdiff) <= bthr * (double)NVK_TIE_ULPS);
                 amb_x |= nr & zr;
                 amb_u |= nr & ur & ~zr;
                 amb_n |= nr & ~ur & ~zr;
               }
             }
 #endif
-            bestn = upd ? dv : bestn;
+            if (upd) {
+              bestn = __builtin_amdgcn_frexp_mant(dv);         // in [0.5, 1)
+              G = Gin - __builtin_amdgcn_frexp_exp(dv);        // its scale; -G = true exponent
+              bthr = bestn * ((double)abs(G) * 0x1.0p-52);
+            }
             bits = (bits << 1) | (upd ? 1u : 0u);  // step u ends up at bit 31 - (u & 31)
             double dpv = bestn * post;  // post is already 0 outside the band
+            int Gd = G;
             if (init_live | top_live) {  // (one scalar test for the two rare cases: the first and the last row)
               asm volatile("");
               if (init_live) {
                 if (is_init) {
                   o = IN_BAND ? ldexp(1.0, sc.L) : 0.0;
                   post = ldexp(o * suf, kap);
-                  dpv = ldexp(post, ps.L);
+                  dpv = post; Gd = 0;
                 }
               }
               if (top_live) {
-                const double fdiff = dpv - fbest, fthr = fbest * cE;
-                {
-                  const unsigned long long nr = __builtin_amdgcn_ballot_w64(r == top && IN_BAND && fabs(fdiff) < dpv * TIE_FLAG_REL);
-                  if (nr != 0) {
-                    asm volatile("");
-                    const unsigned long long zr = __builtin_amdgcn_ballot_w64(fdiff == 0.0);
-                    const unsigned long long ur = __builtin_amdgcn_ballot_w64(fabs(fdiff) <= fthr * (double)NVK_TIE_ULPS);
-                    amb_x |= nr & zr;
-                    amb_u |= nr & ur & ~zr;
-                    amb_n |= nr & ~ur & ~zr;
-                  }
+              const double da = ldexp(dpv, (fbest == 0.0) ? 0 : fG - Gd);
+              {
+                const unsigned long long nr = __builtin_amdgcn_ballot_w64(r == top && IN_BAND && fabs(da - fbest) < da * TIE_FLAG_REL);
+                if (nr != 0) {
+                  asm volatile("");
+                  const unsigned long long zr = __builtin_amdgcn_ballot_w64(da == fbest);
+                  const unsigned long long ur = __builtin_amdgcn_ballot_w64(fabs(da - fbest) <= fthr * (double)NVK_TIE_ULPS);
+                  amb_x |= nr & zr;
+                  amb_u |= nr & ur & ~zr;
+                  amb_n |= nr & ~ur & ~zr;
                 }
-                if (r == top && IN_BAND && (fdiff > fthr)) {
-                  fbest = dpv;
-                  fidx = i;
-                }
+              }
+              if (r == top && IN_BAND && (da - fbest > fthr)) {
+                fbest = dpv;
+                fG = Gd;
+                fidx = i;
+                fthr = dpv * ((double)abs(__builtin_amdgcn_frexp_exp(dpv) - Gd) * 0x1.0p-52);
+              }
               }
             }
             prev = o;
             rsum += post;
 #if NVK_ABL != 7
             *reinterpret_cast<double2 *>(histb + (su * (16 * TL) + gl16)) = make_double2(o, dpv);
+            *reinterpret_cast<int *>(ghistb + (su * (4 * TL) + (gl16 >> 2))) = Gd;
 #endif
             if ((u & 31) == 31) {
               int w = u >> 5;
@@ -1025,8 +989,7 @@ __global__ __launch_bounds__(64 * W, PHASE == 1 ? (W > 1 ? NVK_LB_REV_TEAM : NVK
             // ---- rescale decision for the next step, then the next step's density
             if (W > 1 && age == RS - 2) {  // see the reverse sweep
               const int mxw = wave_max_i((o != 0.0) ? __builtin_amdgcn_frexp_exp(o) : -0x40000000);
-              const int mxp = wave_max_i((bestn != 0.0) ? __builtin_amdgcn_frexp_exp(bestn) : -0x40000000);
-              if (lane == 0) { tmax[wv] = mxw; tmax2[wv] = mxp; }
+              if (lane == 0) tmax[wv] = mxw;
             }
             if (age == RS - 1) {
               suspect |= !(o <= HUGE_V);
@@ -1045,35 +1008,6 @@ __global__ __launch_bounds__(64 * W, PHASE == 1 ? (W > 1 ? NVK_LB_REV_TEAM : NVK
               if (lane == 0 && (mx > -0x40000000) && (TARGET - mx > DMAX))
                 printf("flag fwd rd=%d u=%d/%d mx=%d L=%d RS=%d c=%d T=%d\n", rd, u, n_steps, mx, sc.L, RS, c, T);
 #endif
-              {  // The path scale follows the wave's (team's) largest RUNNING MAXIMUM, not the scores of this one step:
-                 // a cell's score is its row's running maximum times its own posterior, which rises and falls by
-                 // hundreds of bits within a few cells of the path — a snapshot of it would send the scale up
-                 // after an off-path step and the next on-path scores out of range — while the running maxima
-                 // are monotone within a row and grow by at most the posterior's bound from row to row.
-                int mp;
-                if (W == 1) {
-                  mp = wave_max_i((bestn != 0.0) ? __builtin_amdgcn_frexp_exp(bestn) : -0x40000000);
-                } else {
-                  mp = tmax2[0];
-#pragma unroll
-                  for (int w = 1; w < W; w++) mp = max(mp, tmax2[w]);
-                  mp = __builtin_amdgcn_readfirstlane(mp);
-                }
-                // Move the largest running maximum to 2^PTARGET — unless it lies more than PSTEP bits BELOW it: then
-                // only junk is live (at the start of a sweep the first rows see candidates far off the path long
-                // before the path's own scores, thousands of bits larger, arrive), the scale stays, and the junk may
-                // flush.  Real scores change by a few bits per row, so within one period nothing real outruns
-                // PSTEP + 128 bits: no overflow by construction; downward moves are unlimited (what they flush lies
-                // that far below a real score).  Should the path's own scores ever fall out of the range below the
-                // largest one (a team's 256 rows under a very blunt model), they are zeros from that row on, the last
-                // row has no arg-max, and the read goes to the exact kernel (`idx < 0 && K != 0` below).
-                if (mp > -0x40000000 && PTARGET - mp <= PSTEP) {
-                  ps.d_next = PTARGET - mp;
-                  const double ce = (double)abs(mp - ps.L) * 0x1.0p-52;  // |true exponent| of the largest score
-                  cE = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(ce)),
-                                        __builtin_amdgcn_readfirstlane(__double2loint(ce)));
-                }
-              }
               if (PAIR) dsel = em ? sc.d_next : 0;
             }
             i += 1;
@@ -1206,12 +1140,23 @@ int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadM
   void (*k16[3])(Align3Args) = {nullptr, nullptr, nullptr};
   void (*kv[3])(Align3Args) = {nullptr, nullptr, nullptr};
   void (*kt[3])(Align3Args) = {nullptr, nullptr, nullptr};  // teams of ALIGN3_TEAM_W waves (wide bands)
+  void (*kt16[3])(Align3Args) = {nullptr, nullptr, nullptr};  // ... with the rescale period of 16 compiled in
+  // period 8 compiled in: what the sweeps without transition rows use (rsh below); measured on the teams, where a
+  // lockstep step is as long as its longest chain: the compiled-in period folds every test on the step's position
+  // in the period away — forward sweep -16 %, reverse -10 % on BASELINE config 5 reads
+  void (*k8[3])(Align3Args) = {nullptr, nullptr, nullptr};
+  void (*kt8[3])(Align3Args) = {nullptr, nullptr, nullptr};
 #if NVK_TWO_PHASE
 #define A3_SET(M, P)                                                                           \
   do {                                                                                         \
     k16[1] = align3_kernel<M, 4, P, 1, 1>; k16[2] = align3_kernel<M, 4, P, 2, 1>;              \
     kv[1] = align3_kernel<M, 0, P, 1, 1>; kv[2] = align3_kernel<M, 0, P, 2, 1>;                \
     kt[1] = align3_kernel<M, 0, P, 1, ALIGN3_TEAM_W>; kt[2] = align3_kernel<M, 0, P, 2, ALIGN3_TEAM_W>; \
+    kt16[1] = align3_kernel<M, 4, P, 1, ALIGN3_TEAM_W>; kt16[2] = align3_kernel<M, 4, P, 2, ALIGN3_TEAM_W>; \
+    if (!P) {                                                                                   \
+      k8[1] = align3_kernel<M, 3, false, 1, 1>; k8[2] = align3_kernel<M, 3, false, 2, 1>;       \
+      kt8[1] = align3_kernel<M, 3, false, 1, ALIGN3_TEAM_W>; kt8[2] = align3_kernel<M, 3, false, 2, ALIGN3_TEAM_W>; \
+    }                                                                                           \
   } while (0)
 #else
 #define A3_SET(M, P)                                                                           \
@@ -1234,7 +1179,7 @@ int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadM
   // with c <= ALIGN1_C_CAP keep their 16 waves per CU whatever else is in the batch; wide-band reads
   // (long reads, BASELINE config 5) run with larger rings and a longer rescale period.
   // (wide bands: teams of ALIGN3_TEAM_W waves, ReadMeta::cw; their history ring of (cw + mel + 1) slots of
-  // 256 lanes x 16 B has to fit the 160 KB of a CU)
+  // 256 lanes x 20 B has to fit the 160 KB of a CU)
   const int C_HARD = 24;
   struct Cls { int lo, hi; int64_t reads; int W; };
   Cls cls[2];
@@ -1255,9 +1200,9 @@ int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadM
       const int Hc = (cc + mel > 0 ? cc + mel : 1) + (W > 1 ? 1 : 0);
       int SRc = 256;
       while (SRc < 64 * cc + CH) SRc <<= 1;
-      return (size_t)ETN * 8 + (size_t)W * SRc * 8 + (size_t)Hc * TLk * slot_bytes + slot_bytes + 16 + 16 * W;
+      return (size_t)ETN * 8 + (size_t)W * SRc * 8 + (size_t)Hc * TLk * slot_bytes + slot_bytes + 16 + 12 * W;
     };
-    while (c > 1 && lds_need(c, 16) > 160 * 1024) --c;
+    while (c > 1 && lds_need(c, 20) > 160 * 1024) --c;
     // Rescale period 16, or 8 without transition rows: there the last rows of a sweep run through
     // far-off-path cells with nothing slower beside them (the constant-density rows), the wave's
     // largest value collapses ~70 bits per step, and a period of 16 steps overruns the scale-move cap
@@ -1273,7 +1218,7 @@ int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadM
     int SR = 256;
     while (SR < 64 * c + CH) SR <<= 1;  // per wave
     // exp table + the waves' signal rings + history ring (+ its zero entry) + work item / team exchange words
-    const size_t lds = lds_need(c, 16);
+    const size_t lds = lds_need(c, 20);
     const size_t lds_rev = lds_need(c, 8);  // reverse-only launch
     if (lds > 160 * 1024) return NVK_ERR_UNSUPPORTED;
     int per_cu = (int)((160 * 1024) / lds);          // workgroups (waves, or teams of W waves) per CU
@@ -1313,7 +1258,9 @@ int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadM
     g.ties = (int32_t *)ctx->ws[WS_TIES];
     g.out_events = out_events;
     g.out_status = out_status;
-    void (**kern)(Align3Args) = (W > 1) ? kt : ((rsh == 4) ? k16 : kv);
+    // (a team's skew at stride 256 is small: its rescale period is usually the compiled-in 16, BASELINE config 5: 4 + 2)
+    void (**kern)(Align3Args) = (W > 1) ? ((rsh == 4 && kt16[1]) ? kt16 : ((rsh == 3 && kt8[1]) ? kt8 : kt))
+                                        : ((rsh == 4) ? k16 : ((rsh == 3 && k8[1]) ? k8 : kv));
     if (W > 1 && !kern[1]) return NVK_ERR_UNSUPPORTED;  // (one-launch development build)
     for (int ph = 0; ph < 3; ph++)
       if (kern[ph] && (ph == 1 ? lds_rev : lds) > 64 * 1024)

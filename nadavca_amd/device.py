@@ -68,6 +68,30 @@ class DeviceBatch:
         self.total_anchors = int(sa.anc_off[-1])
         return self
 
+    def slice(self, lo, hi, host_off=None):
+        """Reads [lo, hi) as a batch of their own: views of the flat arrays, offsets rebased on the device.
+        ``host_off``: dict of host copies of the five offset arrays (saves five tiny D2H reads per slice)."""
+        torch = self.torch
+        sub = DeviceBatch.__new__(DeviceBatch)
+        sub.torch, sub.device, sub.n = torch, self.device, int(hi - lo)
+        for arr, off, mult in (('signal', 'sig_off', 1), ('reference', 'ref_off', 1), ('context_before', 'cb_off', 1),
+                               ('context_after', 'ca_off', 1), ('anchors', 'anc_off', 2)):
+            o = getattr(self, off)
+            if host_off is not None:
+                a, b = int(host_off[off][lo]), int(host_off[off][hi])
+            else:
+                a, b = int(o[lo]), int(o[hi])
+            flat = getattr(self, arr)
+            piece = flat[mult * a:mult * b]
+            setattr(sub, arr, piece if piece.numel() else torch.zeros(mult, dtype=flat.dtype, device=self.device))
+            setattr(sub, off, (o[lo:hi + 1] - o[lo]).contiguous())
+            if arr in ('signal', 'reference', 'anchors'):
+                setattr(sub, {'signal': 'total_signal', 'reference': 'total_ref', 'anchors': 'total_anchors'}[arr], b - a)
+        return sub
+
+    def host_offsets(self):
+        return {k: getattr(self, k).cpu().numpy() for k in ('sig_off', 'ref_off', 'cb_off', 'ca_off', 'anc_off')}
+
     def pointers(self):
         return [_dp(self.signal), _dp(self.sig_off), _dp(self.reference), _dp(self.ref_off),
                 _dp(self.context_before), _dp(self.cb_off), _dp(self.context_after), _dp(self.ca_off),

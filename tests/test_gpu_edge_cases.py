@@ -294,3 +294,21 @@ def test_little_free_memory_is_served_in_chunks(dtw):
     finally:
         del hog
         torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize('it,case', [(1630, 2), (2828, 2)])
+def test_tiny_posteriors_at_the_end_of_a_short_wide_band_read(dtw, oracle_port, it, case):
+    """tests/dev/fuzz_team.py seed 31415: reads of 85 and 92 bases whose band is wider than the read, min event
+    length 0, random model — the best path ends in several zero-length events with posteriors of ~2^-200 each, so
+    with every row of the read in flight at once the last rows' path scores lie > 900 bits below the first rows'.
+    Round 3's experiment with path scores under ONE wave-uniform scale flushed them and placed the last events
+    hundreds of samples late WITHOUT a tie bit; an exponent per score gives the reference's rows."""
+    from fuzz_cases import make_team_batch, reads_of
+    fb = make_team_batch(31415, it)
+    mg = dtw.KmerModel(*fb['model'])
+    mo = oracle_port.KmerModel(*fb['model'])
+    got = dtw.refine_alignment_batch(reads_of(fb['cases']), fb['bw'], fb['mel'], mg, fb['tr'])
+    c = fb['cases'][case]
+    exp = oracle_port.refine_alignment(c['signal'], c['reference'], c['context_before'], c['context_after'],
+                                       c['approximate_alignment'], fb['bw'], fb['mel'], mo, fb['tr'])
+    assert np.array_equal(got[case], exp)
