@@ -137,7 +137,10 @@ def main():
                     choices=['cfg2_align', 'cfg3_snps', 'cfg4_consensus', 'cfg5_long', 'api_align_signal',
                              'api_estimate_snps'])
     ap.add_argument('--no-tweak', action='store_true', help='api_estimate_snps: tweak_signal_normalization off')
-    ap.add_argument('--fit-workers', type=int, default=16, help='api_estimate_snps: processes for the spline fits')
+    ap.add_argument('--spline-fit', choices=('device', 'host'), default='device',
+                    help='api_estimate_snps: the spline fits on the device (nvk_spline_fit_dev) or by scipy on the host')
+    ap.add_argument('--fit-workers', type=int, default=16,
+                    help='api_estimate_snps --spline-fit host: processes for the spline fits')
     ap.add_argument('--reads', type=int, default=0, help='reads per GPU per step (default: the config size)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-e2e', action='store_true', help='skip the host-pointer legs (profiling runs: their launches '
@@ -205,7 +208,7 @@ def main():
 
             def step():
                 chunks = estimate_snps_batch(genome, rb, config=cfg_snps, kmer_model=km, aligner=aligner,
-                                             fit_workers=args.fit_workers)
+                                             fit_workers=args.fit_workers, spline_fit=args.spline_fit)
                 from nadavca_amd.estimate_snps import last_batch_counts
                 extra['reads_ok'] = last_batch_counts.get('reads_ok')       # status 0 after the log-likelihoods
                 extra['reads_fitted'] = last_batch_counts.get('reads_fitted')
@@ -310,7 +313,8 @@ def main():
                         'band_cells_per_read': round(stats['band_cells'] / n_reads, 1),
                         'wave_steps_per_read': round(stats['wave_steps'] / n_reads, 1)})
         if wname == 'api_estimate_snps':
-            cfg.update({'tweak_signal_normalization': not args.no_tweak, 'fit_workers': args.fit_workers,
+            cfg.update({'tweak_signal_normalization': not args.no_tweak, 'spline_fit': args.spline_fit,
+                        'fit_workers': args.fit_workers if args.spline_fit == 'host' else None,
                         'chunk_groups': extra.get('chunks'), 'reads_spline_fitted': extra.get('reads_fitted')})
         if is_align or wname == 'api_align_signal':
             cfg.update({'reads_redone_exact': stats['reads_redone_exact'],

@@ -306,9 +306,24 @@ int nvk_linfit_rescale_dev(nvk_ctx *ctx, int64_t n_reads, const double *expected
                            const int64_t *ref_off, const int32_t *status, double *signal,
                            const int64_t *sig_off, double *out_fit);
 
+/* replaces the FIT half of Read.tweak_signal_normalization (/root/reference/nadavca/read.py:83-93) for a
+ * batch: per read, keep the events with |expected - means| <= 1, sort the pairs by (mean, level) as
+ * numpy.lexsort((ys, xs)) does, and fit scipy.interpolate.splrep(xs, ys, s=len(xs)).  With that filter and that
+ * s FITPACK's first trial — the least-squares cubic polynomial on the 8 knots [x0]*4 + [x_last]*4 — always meets
+ * its acceptance test (the identity is a cubic and leaves sum (y-x)^2 <= m = s), so no knot is ever placed;
+ * this restates that first pass of fpcurf.f operation for operation (coefficients equal scipy's bit for bit)
+ * and VERIFIES the test per read.  means / expected: f64[total_ref], read j at [ref_off[j], ref_off[j+1]);
+ * status int32[n_reads] or NULL: reads with status != 0 are not fitted.  Outputs per read: out_t f64[8] knots,
+ * out_c f64[8] coefficients (4 + 4 zeros) — the layout nvk_splev_groups_dev takes with knot_off[j] = 8 j —
+ * and out_fit int32: 0 fitted; 1 fewer than 4 usable events (no fit, placeholder spline written: the caller keeps
+ * that read's samples); 2 FITPACK would go on to place knots (NaN input, all means equal: cannot happen under
+ * the filter otherwise) — placeholder written, the caller fits that read with FITPACK itself.  Device pointers. */
+int nvk_spline_fit_dev(nvk_ctx *ctx, int64_t n_reads, int64_t total_ref, const double *means,
+                       const double *expected, const int64_t *ref_off, const int32_t *status, double *out_t,
+                       double *out_c, int32_t *out_fit);
+
 /* replaces scipy.interpolate.splev(x, (t, c, k)) — the evaluation half of
- * Read.tweak_signal_normalization (/root/reference/nadavca/read.py:94; the fit, splrep, stays on the
- * host) — for n_groups groups laid end to end: out[i] = spline_g(x[i]) for i in [grp_off[g], grp_off[g+1]),
+ * Read.tweak_signal_normalization (/root/reference/nadavca/read.py:94; the fit: nvk_spline_fit_dev) — for n_groups groups laid end to end: out[i] = spline_g(x[i]) for i in [grp_off[g], grp_off[g+1]),
  * spline g given by the knots t[knot_off[g] .. knot_off[g+1]) and as many coefficients c[...] as FITPACK
  * returns them, degree k (1..5), extrapolating outside the knots (ext = 0).  FITPACK's splev.f / fpbspl.f
  * restated operation for operation: results equal scipy's bit for bit.  out may alias x.  Device pointers. */

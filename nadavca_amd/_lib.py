@@ -76,6 +76,7 @@ SIGNATURES = {
     'nvk_event_means_dev': (_int, [_vp, _i64, _i64] + [_vp] * 6),
     'nvk_linfit_rescale_dev': (_int, [_vp, _i64] + [_vp] * 7),
     'nvk_splev_groups_dev': (_int, [_vp, _i64] + [_vp] * 5 + [_int, _vp]),
+    'nvk_spline_fit_dev': (_int, [_vp, _i64, _i64] + [_vp] * 7),
 }
 
 _lib = None

@@ -627,7 +627,9 @@ __global__ __launch_bounds__(64 * W, PHASE == 1 ? (W > 1 ? NVK_LB_REV_TEAM : NVK
             mx = __builtin_amdgcn_readfirstlane(mx);
           }
           sc.d_next = (mx > -0x40000000) ? min(TARGET - mx, DMAX) : 0;
-          suspect |= (mx > -0x40000000) && (TARGET - mx > DMAX);
+          // (a capped move matters to the step it is applied to: after the sweep's last step — the padding
+          // behind row 0, where only cells off the band are alive and collapse — there is none)
+          suspect |= (u + 1 < n_steps) && (mx > -0x40000000) && (TARGET - mx > DMAX);
 #ifdef NVK_FLAG_DEBUG
           if (lane == 0 && (mx > -0x40000000) && (TARGET - mx > DMAX || !(o <= HUGE_V)))
             printf("flag rev rd=%d u=%d/%d mx=%d L=%d RS=%d c=%d T=%d\n", rd, u, n_steps, mx, sc.L, RS, c, T);
@@ -1003,7 +1005,7 @@ __global__ __launch_bounds__(64 * W, PHASE == 1 ? (W > 1 ? NVK_LB_REV_TEAM : NVK
                 mx = __builtin_amdgcn_readfirstlane(mx);
               }
               sc.d_next = (mx > -0x40000000) ? min(TARGET - mx, DMAX) : 0;
-              suspect |= (mx > -0x40000000) && (TARGET - mx > DMAX);
+              suspect |= (u + 1 < n_steps) && (mx > -0x40000000) && (TARGET - mx > DMAX);
 #ifdef NVK_FLAG_DEBUG
               if (lane == 0 && (mx > -0x40000000) && (TARGET - mx > DMAX))
                 printf("flag fwd rd=%d u=%d/%d mx=%d L=%d RS=%d c=%d T=%d\n", rd, u, n_steps, mx, sc.L, RS, c, T);

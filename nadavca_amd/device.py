@@ -68,30 +68,6 @@ class DeviceBatch:
         self.total_anchors = int(sa.anc_off[-1])
         return self
 
-    def slice(self, lo, hi, host_off=None):
-        """Reads [lo, hi) as a batch of their own: views of the flat arrays, offsets rebased on the device.
-        ``host_off``: dict of host copies of the five offset arrays (saves five tiny D2H reads per slice)."""
-        torch = self.torch
-        sub = DeviceBatch.__new__(DeviceBatch)
-        sub.torch, sub.device, sub.n = torch, self.device, int(hi - lo)
-        for arr, off, mult in (('signal', 'sig_off', 1), ('reference', 'ref_off', 1), ('context_before', 'cb_off', 1),
-                               ('context_after', 'ca_off', 1), ('anchors', 'anc_off', 2)):
-            o = getattr(self, off)
-            if host_off is not None:
-                a, b = int(host_off[off][lo]), int(host_off[off][hi])
-            else:
-                a, b = int(o[lo]), int(o[hi])
-            flat = getattr(self, arr)
-            piece = flat[mult * a:mult * b]
-            setattr(sub, arr, piece if piece.numel() else torch.zeros(mult, dtype=flat.dtype, device=self.device))
-            setattr(sub, off, (o[lo:hi + 1] - o[lo]).contiguous())
-            if arr in ('signal', 'reference', 'anchors'):
-                setattr(sub, {'signal': 'total_signal', 'reference': 'total_ref', 'anchors': 'total_anchors'}[arr], b - a)
-        return sub
-
-    def host_offsets(self):
-        return {k: getattr(self, k).cpu().numpy() for k in ('sig_off', 'ref_off', 'cb_off', 'ca_off', 'anc_off')}
-
     def pointers(self):
         return [_dp(self.signal), _dp(self.sig_off), _dp(self.reference), _dp(self.ref_off),
                 _dp(self.context_before), _dp(self.cb_off), _dp(self.context_after), _dp(self.ca_off),
@@ -223,6 +199,24 @@ def linfit_rescale_dev(dbatch, context, expected, means, status=None):
         _dp(status) if status is not None else C.c_void_p(0), _dp(dbatch.signal), _dp(dbatch.sig_off),
         _dp(fit)), 'nvk_linfit_rescale_dev')
     return fit
+
+
+def spline_fit_dev(context, means, expected, ref_off, status=None):
+    """The fit of ``Read.tweak_signal_normalization`` (read.py:83-93: keep |expected - mean| <= 1, sort,
+    ``splrep(..., s=len)``) for every read on the device.  means / expected: f64 device tensors, read j at
+    [ref_off[j], ref_off[j+1]); status: int32 per read or None (reads with status != 0 are not fitted).
+    -> (t (n, 8), c (n, 8), fit int32 (n,)): fit 0 = fitted (coefficients equal scipy's), 1 = fewer than 4 usable
+    events, 2 = outside the polynomial case (include/nadavca_hip.h: nvk_spline_fit_dev)."""
+    import torch
+    lib = _lib.load()
+    n = int(ref_off.numel()) - 1
+    t = torch.empty((n, 8), dtype=torch.float64, device=means.device)
+    c = torch.empty((n, 8), dtype=torch.float64, device=means.device)
+    fit = torch.empty(n, dtype=torch.int32, device=means.device)
+    _lib.check(lib.nvk_spline_fit_dev(
+        context.handle, n, int(means.numel()), _dp(means), _dp(expected), _dp(ref_off),
+        _dp(status) if status is not None else C.c_void_p(0), _dp(t), _dp(c), _dp(fit)), 'nvk_spline_fit_dev')
+    return t, c, fit
 
 
 def splev_groups_dev(context, x, grp_off, t, c, knot_off, degree, out=None):

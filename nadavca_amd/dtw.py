@@ -146,20 +146,7 @@ class KmerModel:
         return KmerModel(int(z['k']), int(z['central_pos']), int(z['alphabet_size']), z['mean'], z['sigma'],
                          context=context)
 
-    def lane(self, i):
-        """A copy of this model on a context of its own (own HIP stream and workspaces) — made once and kept —
-        so that a Python thread can run kernels on a chunk of reads beside the main context's (the batch workflows
-        overlap the log-likelihoods of one chunk with the spline fits of the next, estimate_snps.py)."""
-        lanes = self.__dict__.setdefault('_lanes', {})
-        if i not in lanes:
-            ctx = _lib.Context(self.context.device)
-            lanes[i] = KmerModel(self.k, self.central_position, self.alphabet_size, self.mean, self.sigma, context=ctx)
-        return lanes[i]
-
     def close(self):
-        for m in self.__dict__.pop('_lanes', {}).values():
-            m.close()
-            m.context.close()
         if getattr(self, 'handle', None):
             self._lib.nvk_model_destroy(self.handle)
             self.handle = None

@@ -106,96 +106,56 @@ def _apply_splines(context, dbatch, fits):
         dbatch.signal[keep] = saved
 
 
-def _overlap_chunks(n_reads, fit_workers, device=None):
-    """Chunk bounds for the overlapped spline tweak, or None for small batches / in-process fits.  The
-    log-likelihood kernel runs persistent waves, 12 per CU, one read each: a read takes what a read takes (36 ms on
-    config-2 reads) however many run beside it, so a batch costs ceil(reads / wave slots) of those rounds and chunks
-    must be whole rounds — 3 072 reads on an MI355X — or they add rounds; a remainder below half a round joins the
-    last chunk."""
-    if not fit_workers or fit_workers <= 1:
-        return None
+def _apply_device_fits(context, dbatch, t, c, fit):
+    """``signal = splev(signal, spline of its read)`` in place with the splines as nvk_spline_fit_dev left them on
+    the device (8 knots + 8 coefficients per read; reads without a fit carry a placeholder and get their samples
+    back)."""
     import torch
-    cus = torch.cuda.get_device_properties(device).multi_processor_count if device is not None else 256
-    slots = int(os.environ.get('NADAVCA_SNPS_CHUNK_READS', 12 * cus))
-    if n_reads < 2 * slots:
-        return None
-    bounds = list(range(0, n_reads, slots))
-    if n_reads - bounds[-1] < slots // 2:
-        bounds.pop()
-    return bounds + [n_reads]
-
-
-def _tweak_and_ell_overlapped(context, kmer_model, dbatch, config, bounds, fit_workers):
-    """The spline tweak and the log-likelihoods with the host's spline fits (FITPACK, ~0.1 ms per read and core:
-    60-70 ms per 10 000 reads on 16 cores) hidden behind the kernels.  The reads go in chunks (``bounds``: whole rounds of the
-    log-likelihood kernel's wave slots, _overlap_chunks):
-      stage A, this thread and context: pre-alignment without transition rows, expected levels, per-event means ->
-               host, fits handed to the worker processes — first for the first chunk, whose fits start while the
-               rest of the reads is pre-aligned in one piece;
-      stage B, as each chunk's fits arrive: spline evaluation + estimate_log_likelihoods of that chunk on one of two
-               LANES — copies of the model on contexts of their own (KmerModel.lane), each driven by a thread — so
-               that two chunks' persistent waves share the chip (one chunk alone is smaller than its wave slots) while
-               the worker processes fit the chunks behind it.
-    Per read the arithmetic is that of the one-piece path (same kernels, same fits): results identical."""
-    import numpy
-    import queue
-    import torch
-    from concurrent.futures import ThreadPoolExecutor
-    from . import splinefit
-    from .device import (refine_alignment_dev, expected_levels_dev, event_means_dev, estimate_log_likelihoods_dev)
-    bw, mel = config['bandwidth'], config['min_event_length']
+    from .device import splev_groups_dev
     n = dbatch.n
-    hoff = dbatch.host_offsets()
-    n_chunks = len(bounds) - 1
-    ll = torch.zeros((dbatch.total_ref, kmer_model.alphabet_size), dtype=torch.float64, device=dbatch.device)
-    status = torch.zeros(n, dtype=torch.int32, device=dbatch.device)
-    subs = [dbatch.slice(bounds[c], bounds[c + 1], hoff) for c in range(n_chunks)]
-    handles = queue.Queue()
-    n_fitted = [0]
+    knot_off = torch.arange(n + 1, dtype=torch.int64, device=dbatch.device) * 8
+    unfit = fit != 0
+    keep = saved = None
+    if bool(unfit.any()):
+        keep = torch.repeat_interleave(unfit, dbatch.sig_off[1:] - dbatch.sig_off[:-1],
+                                       output_size=dbatch.total_signal)
+        saved = dbatch.signal[keep]
+    splev_groups_dev(context, dbatch.signal, dbatch.sig_off, t.reshape(-1), c.reshape(-1), knot_off, 3,
+                     out=dbatch.signal)
+    if keep is not None:
+        dbatch.signal[keep] = saved
 
-    def stage_a(lo_c, hi_c):
-        """pre-alignment, expected levels, means of chunks [lo_c, hi_c) in one piece; fits submitted per chunk"""
-        lo, hi = bounds[lo_c], bounds[hi_c]
-        piece = subs[lo_c] if hi_c == lo_c + 1 else dbatch.slice(lo, hi, hoff)
-        ev0, st0 = refine_alignment_dev(piece, bw, mel, kmer_model, False)
-        expected = expected_levels_dev(piece, kmer_model, with_contexts=True).cpu().numpy()
-        means = event_means_dev(piece, context, ev0, st0).cpu().numpy()
-        usable = st0.cpu().numpy() == 0
-        r_base = hoff['ref_off'][lo]
-        for c in range(lo_c, hi_c):
-            a, b = bounds[c], bounds[c + 1]
-            ra, rb_ = int(hoff['ref_off'][a] - r_base), int(hoff['ref_off'][b] - r_base)
-            roff = hoff['ref_off'][a:b + 1] - hoff['ref_off'][a]
-            handles.put((c, splinefit.submit_fits(means[ra:rb_], expected[ra:rb_], roff, usable[a - lo:b - lo],
-                                                  workers=fit_workers)))
 
-    def stage_b(c, fits):
-        lane = kmer_model.lane(c % 2)
-        sub = subs[c]
-        _apply_splines(lane.context, sub, fits)
-        r0, r1 = int(hoff['ref_off'][bounds[c]]), int(hoff['ref_off'][bounds[c + 1]])
-        estimate_log_likelihoods_dev(sub, bw, mel, lane, config['model_wobbling'], ll[r0:r1],
-                                     status[bounds[c]:bounds[c + 1]])
-
-    def dispatcher(lanes, jobs):
-        """as each chunk's fits arrive (in chunk order), hand its stage B to a lane"""
-        for _ in range(n_chunks):
-            c, handle = handles.get()
-            fits = handle.result()
-            n_fitted[0] += int(fits[3].sum())
-            jobs.append(lanes.submit(stage_b, c, fits))
-
-    with ThreadPoolExecutor(max_workers=2) as lanes, ThreadPoolExecutor(max_workers=1) as disp:
-        jobs = []
-        d = disp.submit(dispatcher, lanes, jobs)
-        stage_a(0, 1)                      # the small first chunk: its fits start while ...
-        if n_chunks > 1:
-            stage_a(1, n_chunks)           # ... the rest is pre-aligned in one piece
-        d.result()
-        for j in jobs:
-            j.result()
-    last_batch_counts['reads_fitted'] = n_fitted[0]
-    return ll, status
+def _tweak_signal_normalization(context, kmer_model, dbatch, config, fit_workers=0, spline_fit='device'):
+    """``Read.tweak_signal_normalization`` (read.py:83-94) for the batch, in place on its signal: pre-alignment
+    without transition rows, expected levels, per-event means, the fit, the evaluation — five kernels, nothing on
+    the host (``spline_fit='device'``: nvk_spline_fit_dev restates the pass of FITPACK's ``curfit`` that decides
+    these fits and checks per read that it does).  A read the kernel reports as outside that case (fit == 2: NaN
+    levels, all means equal) is fitted by FITPACK itself, as is everything with ``spline_fit='host'`` (scipy in
+    ``fit_workers`` processes — the path of rounds 1-2, kept as the cross-check of the kernel).
+    -> number of reads fitted."""
+    from . import splinefit
+    from .device import refine_alignment_dev, expected_levels_dev, event_means_dev, spline_fit_dev
+    bw, mel = config['bandwidth'], config['min_event_length']
+    ev0, st0 = refine_alignment_dev(dbatch, bw, mel, kmer_model, False)
+    expected = expected_levels_dev(dbatch, kmer_model, with_contexts=True)
+    means = event_means_dev(dbatch, context, ev0, st0)
+    if spline_fit == 'device':
+        t, c, fit = spline_fit_dev(context, means, expected, dbatch.ref_off, st0)
+        beyond = fit == 2
+        if not bool(beyond.any()):
+            _apply_device_fits(context, dbatch, t, c, fit)
+            return int((fit == 0).sum())
+        fits = splinefit.merge_host_fits(means.cpu().numpy(), expected.cpu().numpy(),
+                                         dbatch.ref_off.cpu().numpy(), t.cpu().numpy(), c.cpu().numpy(),
+                                         fit.cpu().numpy())
+    elif spline_fit == 'host':
+        fits = splinefit.fit_splines(means.cpu().numpy(), expected.cpu().numpy(), dbatch.ref_off.cpu().numpy(),
+                                     st0.cpu().numpy() == 0, workers=fit_workers)
+    else:
+        raise ValueError("spline_fit: 'device' or 'host'")
+    _apply_splines(context, dbatch, fits)
+    return int(fits[3].sum())
 
 
 # what the last estimate_snps_batch call saw (bench.py reports it): reads in the batch, reads with an approximate
@@ -220,12 +180,12 @@ class IndependentChunks:
 
 def estimate_snps_batch(reference_num, read_batch, config=defaults.CONFIG_FILE,
                         kmer_model=defaults.KMER_MODEL_FILE, independent=False, aligner=None, fit_workers=0,
-                        group=None, distributed=None, dst=0, overlap_chunks=None):
+                        group=None, distributed=None, dst=0, spline_fit='device'):
     """``estimate_snps`` for a struct-of-arrays ``ReadBatch`` (nadavca_amd/readbatch.py) without per-read
     Python: the steps of estimate_snps.py:57-70 and estimator.py:59-121,199-236 — ONE median/MAD over all
     reads, approximate alignment, the spline tweak (pre-alignment without transition rows, expected levels,
-    per-event means, FIT on the host — nadavca_amd/splinefit.py, ``fit_workers`` processes — evaluation on the
-    device), log-likelihoods, normalise / strand-flip / per-position sum, grouping, posterior — with the
+    per-event means, fit — nvk_spline_fit_dev; ``spline_fit='host'`` sends it to scipy in ``fit_workers``
+    processes instead, nadavca_amd/splinefit.py — and evaluation, all on the device), log-likelihoods, normalise / strand-flip / per-position sum, grouping, posterior — with the
     signals, the sums and everything between them resident on the device.
     ``reference_num``: the reference as base codes; ``aligner``: as for ``align_signal_batch``.
     -> list of Chunk (consensus) or IndependentChunks.
@@ -239,7 +199,7 @@ def estimate_snps_batch(reference_num, read_batch, config=defaults.CONFIG_FILE,
     elsewhere); ``independent=True`` returns every rank's own IndependentChunks."""
     import numpy
     import torch
-    from . import readbatch, splinefit
+    from . import readbatch
     from .device import (DeviceBatch, normalize_groups_dev, refine_alignment_dev, expected_levels_dev,
                          event_means_dev, estimate_log_likelihoods_dev, consensus_accumulate_dev,
                          posterior_segments_dev)
@@ -292,30 +252,10 @@ def estimate_snps_batch(reference_num, read_batch, config=defaults.CONFIG_FILE,
         cov = torch.zeros(L, dtype=torch.int64, device=device)
         return _consensus_chunks(context, kmer_model, config, reference_num, acc, cov, [], device, True, group, dst)
     dbatch = DeviceBatch.from_windows(norm, sa, device)
-    # (overlap_chunks: None = automatic — whole rounds of the log-likelihood kernel's wave slots, from two rounds on,
-    # when the fits run in worker processes; an int forces that many equal chunks)
-    bounds = None
     if config['tweak_signal_normalization']:
-        if overlap_chunks is None:
-            bounds = _overlap_chunks(n_live, fit_workers, device)
-        elif int(overlap_chunks) > 1:
-            k_ = min(int(overlap_chunks), n_live)
-            bounds = [(n_live * c) // k_ for c in range(k_ + 1)]
-    if bounds is not None:
-        ll, status = _tweak_and_ell_overlapped(context, kmer_model, dbatch, config, bounds, fit_workers)
-    else:
-        if config['tweak_signal_normalization']:
-            # read.py:83-94: pre-alignment without transition rows, expected levels, per-event means (kernels);
-            # keep / sort / splrep per read (host); splev over the windows (kernel)
-            ev0, st0 = refine_alignment_dev(dbatch, bw, mel, kmer_model, False)
-            expected = expected_levels_dev(dbatch, kmer_model, with_contexts=True)
-            means = event_means_dev(dbatch, context, ev0, st0)
-            ref_off_h = sa.ref_off.cpu().numpy()
-            fits = splinefit.fit_splines(means.cpu().numpy(), expected.cpu().numpy(), ref_off_h,
-                                         st0.cpu().numpy() == 0, workers=fit_workers)
-            last_batch_counts['reads_fitted'] = int(fits[3].sum())
-            _apply_splines(context, dbatch, fits)
-        ll, status = estimate_log_likelihoods_dev(dbatch, bw, mel, kmer_model, config['model_wobbling'])
+        last_batch_counts['reads_fitted'] = _tweak_signal_normalization(context, kmer_model, dbatch, config,
+                                                                        fit_workers, spline_fit)
+    ll, status = estimate_log_likelihoods_dev(dbatch, bw, mel, kmer_model, config['model_wobbling'])
     _check_status('estimate_log_likelihoods', status, sa.live)
     rev32 = sa.reverse.to(torch.int32)
     nel = config['normalization_event_length']

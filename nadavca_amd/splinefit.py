@@ -1,9 +1,11 @@
-"""The FIT half of ``Read.tweak_signal_normalization`` (/root/reference/nadavca/read.py:83-93) for many reads:
-per read, keep the events whose mean lies within 1 of the model's expected level, sort the pairs by mean and fit
-FITPACK's smoothing spline (``scipy.interpolate.splrep(means, expected, s=len(means))``).  It is the one numerical
-step of the workflows that stays on the host — FITPACK's ``curfit`` is an adaptive knot-placement iteration —
-and at ~0.25 ms per read it is what bounds ``estimate_snps`` once everything else is a kernel; the reads are
-independent, so the fits are spread over worker processes (scipy holds the GIL inside the call)."""
+"""The FIT half of ``Read.tweak_signal_normalization`` (/root/reference/nadavca/read.py:83-93) for many reads ON
+THE HOST, with scipy: per read, keep the events whose mean lies within 1 of the model's expected level, sort the
+pairs by mean and fit FITPACK's smoothing spline (``scipy.interpolate.splrep(means, expected, s=len(means))``).
+Since round 3 the batch path fits on the device (``nvk_spline_fit_dev``, csrc/splfit.h: under that filter and
+that ``s`` FITPACK never gets past its first trial, the least-squares cubic); this module is what serves a read the
+kernel reports as outside that case, the per-read ``Read.tweak_signal_normalization``, and
+``estimate_snps_batch(spline_fit='host')`` — the cross-check of the kernel (~0.25 ms per read; the reads are
+independent, so the fits are spread over worker processes: scipy holds the GIL inside the call)."""
 import numpy as np
 
 
@@ -65,12 +67,31 @@ class FitHandle:
         for j in self.local:
             means, expected, ref_off, _ = self._retry
             results[j] = fit_one(means[ref_off[j]:ref_off[j + 1]], expected[ref_off[j]:ref_off[j + 1]])
-        fitted = np.array([r is not None for r in results], dtype=bool)
-        lens = np.array([len(r[0]) if r is not None else 0 for r in results], dtype=np.int64)
-        knot_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
-        t = np.concatenate([r[0] for r in results if r is not None]) if fitted.any() else np.zeros(0)
-        c = np.concatenate([r[1] for r in results if r is not None]) if fitted.any() else np.zeros(0)
-        return t, c, knot_off, fitted
+        return pack_results(results)
+
+
+def pack_results(results):
+    """per-read (t, c) or None -> (t, c, knot_off, fitted) laid end to end"""
+    fitted = np.array([r is not None for r in results], dtype=bool)
+    lens = np.array([len(r[0]) if r is not None else 0 for r in results], dtype=np.int64)
+    knot_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    t = np.concatenate([r[0] for r in results if r is not None]) if fitted.any() else np.zeros(0)
+    c = np.concatenate([r[1] for r in results if r is not None]) if fitted.any() else np.zeros(0)
+    return t, c, knot_off, fitted
+
+
+def merge_host_fits(means, expected, ref_off, t8, c8, fit):
+    """The device's fits (t8, c8: (n, 8); fit: 0 fitted, 1 no fit, 2 outside the kernel's case) with the reads of
+    class 2 fitted here by FITPACK -> (t, c, knot_off, fitted) as ``fit_splines`` returns them."""
+    results = []
+    for j in range(len(fit)):
+        if fit[j] == 0:
+            results.append((t8[j], c8[j]))
+        elif fit[j] == 1:
+            results.append(None)
+        else:
+            results.append(fit_one(means[ref_off[j]:ref_off[j + 1]], expected[ref_off[j]:ref_off[j + 1]]))
+    return pack_results(results)
 
 
 def submit_fits(means, expected, ref_off, usable, workers=0):

@@ -293,27 +293,3 @@ def test_detect_meth_rows(km, tmp_path):
         got = np.array(row[3].split(','), dtype=float)
         assert np.allclose(got, sc, rtol=1e-12, atol=0)
         assert float(row[4]) == pytest.approx(max(sum(sc[i:i + 3]) for i in range(9)), rel=1e-12)
-
-
-def test_overlapped_spline_tweak_equals_the_one_piece_path(km):
-    """``estimate_snps_batch`` with the spline fits hidden behind the kernels — reads in chunks, stage A
-    (pre-alignment, means, fits handed to worker processes) on the main context, stage B (spline evaluation +
-    log-likelihoods) on two lanes driven by threads — against the same call in one piece: identical chunks."""
-    from nadavca_amd import synthetic
-    from nadavca_amd.estimate_snps import estimate_snps_batch, last_batch_counts
-    model = synthetic.load_model_arrays()
-    rb, aligner, genome = synthetic.make_read_batch(360, model, seed=91, genome_length=3000, length=220, spread=40,
-                                                    substitution_rate=0.03)
-    cfg = dict(bandwidth=150, snp_prior_probability=0.001, min_event_length=2, model_wobbling=True,
-               model_transitions=True, tweak_signal_normalization=True, normalization_event_length=10)
-    one = estimate_snps_batch(genome, rb, config=cfg, kmer_model=km, aligner=aligner, fit_workers=0, overlap_chunks=1)
-    fitted_one = last_batch_counts['reads_fitted']
-    for workers in (0, 2):
-        got = estimate_snps_batch(genome, rb, config=cfg, kmer_model=km, aligner=aligner, fit_workers=workers,
-                                  overlap_chunks=3)
-        assert last_batch_counts['reads_fitted'] == fitted_one and last_batch_counts['reads_ok'] == 360
-        assert len(got) == len(one) >= 1
-        for a, b in zip(got, one):
-            assert (a.start, a.end) == (b.start, b.end)
-            assert np.array_equal(a.coverage, b.coverage)
-            assert np.max(np.abs(a.values - b.values)) < 1e-12     # (f64 atomics: the order of the sums differs)

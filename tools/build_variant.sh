@@ -16,5 +16,5 @@ if [ -n "$APIDEBUG" ]; then  # api.hip with the debug switches (NADAVCA_ALIGN3_N
   API=api_dbg.o
 fi
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $ROOT/variants/lib_$NAME.so $API $C/pipeline.o $C/kernels_plan.o \
-  $C/kernels_align.o a3.o $C/kernels_ell.o $C/kernels_consensus.o $C/kernels_renorm.o
+  $C/kernels_align.o a3.o $C/kernels_ell.o $C/kernels_consensus.o $C/kernels_renorm.o $C/kernels_splfit.o
 echo "built $NAME: $(grep 'align3_kernelILi2ELi4ELb[01]E.*num_vgpr' kernels_align3-hip-amdgcn-amd-amdhsa-gfx950.s | sed 's/.*num_vgpr, /vgpr /')"
