@@ -95,6 +95,8 @@ struct HypDesc {
   int wbs, wbe;         // cells of the wobble row (what arrives from the left is taken from wbs on)
   int elo, ebe;         // cells of the emitting row
   int has_wob;
+  double wmul;          // phase C: exp(-2) on a lane with a wobble row, 0 without ...
+  int wexp;             // ... and 0 / XZ: the mixture times (wmul, wexp) is the mixture or a clean zero
 };
 
 // a + b without re-normalising the mantissa (it drifts by a few bits per step at most; the caller
@@ -140,6 +142,36 @@ __device__ __forceinline__ X fused_step_fast(const HypDesc &d, LaneState<MEL> &s
     st.gh[0] = gb;
   }
   return en;
+}
+
+// fused_step_fast with the wobble history as a ring: the value of step u lives in wq[u % (MEL+1)] (r, a constant
+// once the caller's trip of lcm(PF, MEL+1) steps is unrolled), so no register moves between steps
+template <int MEL>
+__device__ __forceinline__ void fused_step_ring(const HypDesc &d, LaneState<MEL> &st, int r, int i, X gb, X ga,
+                                                X pred) {
+  constexpr int M = MEL + 1;
+  // (g1 + g2) * exp(-2), or a zero without a wobble row — by multiplication: both densities are finite here (a
+  // lane's own, and its left neighbour's through the DPP move, whose fill value is 0), so 0 * mix is 0
+  X mix = add_lazy(ga, gb);
+  mix.m = mix.m * d.wmul;
+  mix.e = mix.e + d.wexp;
+  X wn = add_lazy(pred, xm::mul(mix, st.wq[(r + M - 1) % M]));
+  wn = xm::sel(i >= d.wbs && i <= d.wbe, wn, xm::zero());
+  st.wq[r] = wn;  // replaces the value of step u - M; the one of step u - MEL is wq[(r + 1) % M]
+  X P = xm::one();
+  if (MEL >= 1) {
+    P = gb;
+#pragma unroll
+    for (int k = 0; k < MEL - 1; k++) P = xm::mul(P, st.gh[k]);
+  }
+  X en = add_lazy(xm::mul(P, st.wq[(r + 1) % M]), xm::mul(gb, st.em));
+  en = xm::sel(i >= d.elo && i <= d.ebe, en, xm::zero());
+  st.em = en;
+  if (MEL >= 2) {
+#pragma unroll
+    for (int k = MEL - 2; k >= 1; k--) st.gh[k] = st.gh[k - 1];
+    st.gh[0] = gb;
+  }
 }
 
 // value of the previous lane (DPP row_shr:1 with bound_ctrl: the first lane of each 16-lane row
@@ -507,6 +539,12 @@ __global__ __launch_bounds__(64, 3) void ell_kernel(EllArgs g) {
       continue;
     }
     const double *sig = g.a.signal + m.sig_off;
+    const char *sig_u;  // the same address as a scalar (phase C loads with scalar base + 32-bit lane offset)
+    {
+      const unsigned long long a = (unsigned long long)sig;
+      sig_u = (const char *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
+                             (unsigned)__builtin_amdgcn_readfirstlane((int)a));
+    }
     const int32_t *ref = g.a.reference + m.ref_off;
     const int nb = (int)(g.a.cb_off[rd + 1] - g.a.cb_off[rd]);
     const int na = (int)(g.a.ca_off[rd + 1] - g.a.ca_off[rd]);
@@ -621,6 +659,8 @@ __global__ __launch_bounds__(64, 3) void ell_kernel(EllArgs g) {
           dens::scale_consts(dm.ac[idb], dm.mc[idb], d.bac, d.bmc);
         }
         d.elo = max(d.wbs, MEL);
+        d.wmul = d.has_wob ? EXPM2_D : 0.0;
+        d.wexp = d.has_wob ? 0 : xm::XZ;
         const int base = valid ? bs[first] : 0;
         int steps = 0;
         if (is_fin) steps = d.wbe - base + gl + 1;
@@ -629,7 +669,14 @@ __global__ __launch_bounds__(64, 3) void ell_kernel(EllArgs g) {
         const int i0 = base - gl;
         // clamped, unsigned element offsets from uniform base pointers (scalar base + 32-bit offset)
         auto sidx = [&](int i) { return (unsigned)((i >= slo && i <= shi) ? sbase + i : smax); };
-        auto xidx = [&](int i) { return (unsigned)min(max(i - 1, 0), N - 1); };
+        // sample s[i-1] of cell i, clamped into the read (cells beyond it are outside every band): a byte offset
+        // from the read's uniform base pointer, one v_med3 per load
+        const int xhi = 8 * (N - 1);
+        auto xload = [&](int i) {
+          int off;
+          asm("v_med3_i32 %0, %1, 0, %2" : "=v"(off) : "v"(8 * (i - 1)), "s"(xhi));
+          return *reinterpret_cast<const double *>(sig_u + (unsigned)off);
+        };
         LaneState<MEL> st;
         st.reset();
         X acc = xm::zero(), gb_last = xm::one();
@@ -637,38 +684,47 @@ __global__ __launch_bounds__(64, 3) void ell_kernel(EllArgs g) {
         int ce[PF];
 #pragma unroll
         for (int q = 0; q < PF; q++) {
-          cx[q] = sig[xidx(i0 + q)];
+          cx[q] = xload(i0 + q);
           cm[q] = pre_m[sidx(i0 + q)];
           ce[q] = pre_e[sidx(i0 + q)];
         }
-        for (int ub = 0; ub < steps; ub += PF) {
+        // a trip = lcm(PF, MEL + 1) steps, unrolled: prefetch slot and history slot of every step are constants.
+        // The steps are rounded up to whole trips (the extra cells lie beyond every band: zeros, zero cell).
+        // (min event length 4: 20 steps per trip are more than the register allocator survives; that variant
+        // keeps PF steps per trip and shifts its history)
+        constexpr int M = MEL + 1;
+        constexpr bool RING = (PF % M == 0) || PF * M <= 12;
+        constexpr int TRIP = (!RING || PF % M == 0) ? PF : PF * M;
+        constexpr int NRM = (11 / TRIP + 1) * TRIP;  // steps between mantissa normalisations: whole trips, >= 12
+        for (int ub = 0; ub < steps; ub += TRIP) {
 #pragma unroll
-          for (int q = 0; q < PF; q++) {
-            const int u = ub + q;
-            if (u < steps) {
-              const int i = i0 + u;
-              if ((u & (HRS - 1)) == HRS - 1) {  // keep the lazily summed mantissas near 1
-                asm volatile("");
-#pragma unroll
-                for (int k = 0; k <= MEL; k++) st.wq[k] = xm::norm(st.wq[k]);
-                st.em = xm::norm(st.em);
-                acc = xm::norm(acc);
-              }
-              const X sv{cm[q], ce[q]};  // zero outside the stream's band (zero cell)
-              const X ga = dpp_shr1(gb_last);
-              // the emitting row of the lane to the left, one step ago: zero beyond its last cell, and
-              // only taken from the wobble row's first cell on
-              X pred = dpp_shr1(st.em);
-              if (is_in) pred = sv;  // prefix[first]
-              const X gb = density_x(cx[q], d.bm, d.bac, d.bmc, etab);
+          for (int w = 0; w < TRIP; w++) {
+            const int q = w % PF, r = w % M;
+            const int u = ub + w;
+            const int i = i0 + u;
+            const X sv{cm[q], ce[q]};  // zero outside the stream's band (zero cell)
+            const X ga = dpp_shr1(gb_last);
+            // the emitting row of the lane to the left, one step ago: zero beyond its last cell, and
+            // only taken from the wobble row's first cell on
+            X pred = dpp_shr1(st.em);
+            if (is_in) pred = sv;  // prefix[first]
+            const X gb = density_x(cx[q], d.bm, d.bac, d.bmc, etab);
+            if constexpr (RING)
+              fused_step_ring<MEL>(d, st, r, i, gb, ga, pred);
+            else
               (void)fused_step_fast<MEL>(d, st, i, gb, ga, pred);
-              gb_last = gb;
-              // node.cpp:31-37; only the closing lane's total is used (the other lanes sum garbage)
-              acc = add_lazy(acc, xm::mul(st.wq[0], sv));
-              cx[q] = sig[xidx(i0 + u + PF)];
-              cm[q] = pre_m[sidx(i0 + u + PF)];
-              ce[q] = pre_e[sidx(i0 + u + PF)];
-            }
+            gb_last = gb;
+            // node.cpp:31-37; only the closing lane's total is used (the other lanes sum garbage)
+            acc = add_lazy(acc, xm::mul(st.wq[RING ? r : 0], sv));
+            cx[q] = xload(i0 + u + PF);
+            cm[q] = pre_m[sidx(i0 + u + PF)];
+            ce[q] = pre_e[sidx(i0 + u + PF)];
+          }
+          if ((ub + TRIP) % NRM == 0) {  // keep the lazily summed mantissas near 1
+#pragma unroll
+            for (int k = 0; k <= MEL; k++) st.wq[k] = xm::norm(st.wq[k]);
+            st.em = xm::norm(st.em);
+            acc = xm::norm(acc);
           }
         }
         if (is_fin) out[(size_t)p * alpha + b] = xm::to_log(xm::norm(acc));

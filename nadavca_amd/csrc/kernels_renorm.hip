@@ -5,7 +5,7 @@
 //   nvk_event_means_dev        the per-event numpy.mean         nadavca/align_signal.py:66-69, read.py:85-86
 //   nvk_linfit_rescale_dev     scipy.stats.linregress + rescale nadavca/align_signal.py:71-73
 //   nvk_splev_groups_dev       scipy.interpolate.splev          nadavca/read.py:94 (the spline tweak's evaluation;
-//                              the fit, FITPACK's splrep, stays on the host)
+//                              the fit, FITPACK's splrep: kernels_splfit.hip)
 //
 // All three are byte/HBM-bound passes over the signal (8 B per sample) — no MFMA, no LDS tiling.
 // Exactness: the medians are exact selections (radix select on the order-preserving integer image of
