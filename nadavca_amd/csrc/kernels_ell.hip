@@ -47,6 +47,7 @@
 #include <math.h>
 
 #include "nvk_internal.h"
+#include "variant_switches.h"
 #include "xmath.h"
 #include "dens.h"
 
@@ -115,7 +116,7 @@ __device__ __forceinline__ X density_x(double x, double mean, double ac, double 
 // fused_step with lazy sums; gb/ga are the two mixture components at this cell's sample
 template <int MEL>
 __device__ __forceinline__ X fused_step_fast(const HypDesc &d, LaneState<MEL> &st, int i, X gb, X ga,
-                                             X pred) {
+                                             X pred, X alt) {
   // (g1 + g2) * exp(-2).  Without a wobble row the factor is a clean zero by SELECT: what arrives
   // as `ga` may then be anything (LDS left-overs, the DPP fill value), including NaN, and 0 * NaN
   // would leak it into the row.
@@ -134,7 +135,7 @@ __device__ __forceinline__ X fused_step_fast(const HypDesc &d, LaneState<MEL> &s
     for (int k = 0; k < MEL - 1; k++) P = xm::mul(P, st.gh[k]);
   }
   X en = add_lazy(xm::mul(P, st.wq[MEL]), xm::mul(gb, st.em));
-  en = xm::sel(i >= d.elo && i <= d.ebe, en, xm::zero());
+  en = xm::sel(i >= d.elo && i <= d.ebe, en, alt);  // alt: a zero (the sweeps), the lane's stream (phase C)
   st.em = en;
   if (MEL >= 2) {
 #pragma unroll
@@ -148,7 +149,7 @@ __device__ __forceinline__ X fused_step_fast(const HypDesc &d, LaneState<MEL> &s
 // once the caller's trip of lcm(PF, MEL+1) steps is unrolled), so no register moves between steps
 template <int MEL>
 __device__ __forceinline__ void fused_step_ring(const HypDesc &d, LaneState<MEL> &st, int r, int i, X gb, X ga,
-                                                X pred) {
+                                                X pred, X alt) {
   constexpr int M = MEL + 1;
   // (g1 + g2) * exp(-2), or a zero without a wobble row — by multiplication: both densities are finite here (a
   // lane's own, and its left neighbour's through the DPP move, whose fill value is 0), so 0 * mix is 0
@@ -158,14 +159,18 @@ __device__ __forceinline__ void fused_step_ring(const HypDesc &d, LaneState<MEL>
   X wn = add_lazy(pred, xm::mul(mix, st.wq[(r + M - 1) % M]));
   wn = xm::sel(i >= d.wbs && i <= d.wbe, wn, xm::zero());
   st.wq[r] = wn;  // replaces the value of step u - M; the one of step u - MEL is wq[(r + 1) % M]
-  X P = xm::one();
+  X en;
   if (MEL >= 1) {
-    P = gb;
+    // e(s_i) * (e(s_{i-1}) .. e(s_{i-MEL+1}) * wobble[i-MEL] + emitting[i-1]): the newest density taken out of both
+    // terms (two multiplications fewer than product-first; the rounding differs in the last bit)
+    X Q = st.wq[(r + 1) % M];
 #pragma unroll
-    for (int k = 0; k < MEL - 1; k++) P = xm::mul(P, st.gh[k]);
+    for (int k = 0; k < MEL - 1; k++) Q = xm::mul(Q, st.gh[k]);
+    en = xm::mul(gb, add_lazy(Q, st.em));
+  } else {
+    en = add_lazy(st.wq[(r + 1) % M], xm::mul(gb, st.em));
   }
-  X en = add_lazy(xm::mul(P, st.wq[(r + 1) % M]), xm::mul(gb, st.em));
-  en = xm::sel(i >= d.elo && i <= d.ebe, en, xm::zero());
+  en = xm::sel(i >= d.elo && i <= d.ebe, en, alt);  // alt: the lane's stream at this cell (see the caller)
   st.em = en;
   if (MEL >= 2) {
 #pragma unroll
@@ -472,7 +477,7 @@ __device__ void sweep_fast(const FusedParam *desc, int R, int N, int c, const do
     // that dominates the sums it enters passes its mantissa on, so any systematic factor per hand-over
     // (the 0.5 of xm::one() with mel = 0, the emission product's mantissa otherwise) would compound to
     // 2^-R or 2^+R along the lanes, whatever the lanes do to their own registers in between.
-    (void)fused_step_fast<MEL>(d, st, i, gb, ga, pred);
+    (void)fused_step_fast<MEL>(d, st, i, gb, ga, pred, xm::zero());
     st.em = xm::norm(st.em);
     const X en = st.em;
     const int hw = su * 64 + lane;
@@ -564,7 +569,8 @@ __global__ __launch_bounds__(64, 3) void ell_kernel(EllArgs g) {
       suf_e[rowoff[R] + x - bs[R]] = 1;
     }
     // ---- A, B: the two sweeps
-    if (FAST) {
+    if (NVK_ELL_ABL == 2) {
+    } else if (FAST) {
       SweepLane *ltab = reinterpret_cast<SweepLane *>(tab);  // same window, smaller entries
       sweep_fast<MEL>(g.pl.fwd + m.row_off, R, N, c, sig, false, ring, RM, ltab, etab, hist_m, hist_g,
                       hist_e, g.H, pre_m, pre_e, lane);
@@ -598,7 +604,8 @@ __global__ __launch_bounds__(64, 3) void ell_kernel(EllArgs g) {
     const int back = dm.k - dm.central - 1, fwd = dm.central;
     const int n_items = R * (alpha - 1);
     const int grp = lane / GL, gl = lane % GL;
-    if (FAST) {
+    if (NVK_ELL_ABL == 1) {
+    } else if (FAST) {
       // lane roles in a group: 0 = density of the k-mer before `first` (only feeds the mixture of the
       // first position), 1..npos = the positions first..last, npos+1 = the closing lane.
       // Lane role rho is at cell i = base + u - rho at step u, so whatever lane rho-1 produced at step
@@ -618,7 +625,6 @@ __global__ __launch_bounds__(64, 3) void ell_kernel(EllArgs g) {
         }
         const bool is_pos = valid && gl >= 1 && gl <= npos;
         const bool is_fin = valid && gl == npos + 1;
-        const bool is_in = valid && gl == 1;  // the lane fed by prefix[first]
         HypDesc d;
         d.wbs = 0x40000000; d.wbe = -0x40000000; d.elo = 0x40000000; d.ebe = -0x40000000;
         d.has_wob = 0; d.bm = 0.0; d.bac = 0.0; d.bmc = 0.0;
@@ -629,15 +635,16 @@ __global__ __launch_bounds__(64, 3) void ell_kernel(EllArgs g) {
         int64_t idb = -1;
         if (valid && gl == 0) {
           if (first > 0 && g.wobbling) idb = kmer_id_mod(dm, ref, R, cb, nb, ca, na, first - 1, p, b);
+          // this lane also carries prefix[first] to the first position: its rows are empty, so what it keeps as
+          // "emitting value" is the alternative of the band select — its stream at the cell it is on, which is
+          // the cell the lane to its right works on one step later
+          sbase = rowoff[first] - bs[first];
+          slo = bs[first]; shi = be[first];
         } else if (is_pos) {
           const int j = first + gl - 1;
           idb = kmer_id_mod(dm, ref, R, cb, nb, ca, na, j, p, b);
           d.has_wob = (j > 0 && g.wobbling) ? 1 : 0;
           d.wbs = bs[j]; d.wbe = be[j]; d.ebe = be[j + 1];
-          if (is_in) {
-            sbase = rowoff[first] - bs[first];
-            slo = bs[first]; shi = be[first];
-          }
         } else if (is_fin) {
           // closing lane: optional wobble row on band `last` (quirk), predecessor = emitting row of
           // position `last` on band last+1; then the running total against suffix[last+1]
@@ -704,15 +711,16 @@ __global__ __launch_bounds__(64, 3) void ell_kernel(EllArgs g) {
             const int i = i0 + u;
             const X sv{cm[q], ce[q]};  // zero outside the stream's band (zero cell)
             const X ga = dpp_shr1(gb_last);
-            // the emitting row of the lane to the left, one step ago: zero beyond its last cell, and
-            // only taken from the wobble row's first cell on
-            X pred = dpp_shr1(st.em);
-            if (is_in) pred = sv;  // prefix[first]
+            // the emitting row of the lane to the left, one step ago: zero beyond its last cell, and only taken
+            // from the wobble row's first cell on; for the first position that lane is role 0, which hands
+            // prefix[first] over.  Outside its emitting row a lane keeps `sv` instead of a zero: the zero cell for
+            // every position lane (they have no stream), the stream for role 0, and nobody reads the closing lane's
+            const X pred = dpp_shr1(st.em);
             const X gb = density_x(cx[q], d.bm, d.bac, d.bmc, etab);
             if constexpr (RING)
-              fused_step_ring<MEL>(d, st, r, i, gb, ga, pred);
+              fused_step_ring<MEL>(d, st, r, i, gb, ga, pred, sv);
             else
-              (void)fused_step_fast<MEL>(d, st, i, gb, ga, pred);
+              (void)fused_step_fast<MEL>(d, st, i, gb, ga, pred, sv);
             gb_last = gb;
             // node.cpp:31-37; only the closing lane's total is used (the other lanes sum garbage)
             acc = add_lazy(acc, xm::mul(st.wq[RING ? r : 0], sv));
@@ -889,13 +897,9 @@ int launch_ell(nvk_ctx *ctx, const DeviceModel &dm, const BatchArgs &a, int wobb
   if (per_cu < 1) per_cu = 1;
   int64_t slots = ctx->slots_override > 0 ? ctx->slots_override : (int64_t)ctx->num_cus * per_cu;
   if (slots > a.n_reads) slots = a.n_reads;
-  // This kernel is VALU-bound (80 % busy at 10 waves per CU already), so waves beyond that buy nothing;
-  // what matters is that the persistent waves end together: use no more slots than the number of
-  // rounds needs (10 000 reads: 4 rounds of 2 500 instead of 3.26 rounds of 3 072, measured -2.5 %).
-  if (ctx->slots_override <= 0 && slots > 0) {
-    const int64_t rounds = (a.n_reads + slots - 1) / slots;
-    slots = (a.n_reads + rounds - 1) / rounds;
-  }
+  // (Round 2 used no more slots than whole rounds of reads need — 10 000 reads: 4 rounds of 2 500 — because the
+  // waves then end together; since the hypothesis loop issues a tenth fewer instructions the third wave per SIMD is
+  // worth more than the even finish: 3 072 slots 105.5 ms, 2 500 slots 110.5 ms, 3 328 / 3 584 no better.)
   const int64_t half = (int64_t)(tot.max_W > 0 ? tot.max_W : 1) + 64;
   const int64_t stride = 2 * half;
   const int64_t cap = nvk_spill_cap(ctx, WS_SPILL);
