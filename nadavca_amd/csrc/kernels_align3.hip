@@ -1299,6 +1299,8 @@ int launch_align3(nvk_ctx *ctx, const BatchArgs &a, int transitions, const ReadM
       if (rc) return rc;
       int64_t slots_f = ctx->slots_override > 0 ? ctx->slots_override : (int64_t)ctx->num_cus * per_cu;
       int64_t slots_r = ctx->slots_override > 0 ? ctx->slots_override : (int64_t)ctx->num_cus * per_cu_rev;
+      if (NVK_SLOTS_F > 0) slots_f = NVK_SLOTS_F;
+      if (NVK_SLOTS_R > 0) slots_r = NVK_SLOTS_R;
       if (slots_f > n_chunk) slots_f = n_chunk;
       if (slots_r > n_chunk) slots_r = n_chunk;
       rc = nvk_ws_reserve(ctx, WS_BP, (size_t)slots_f * bp_stride * 4);

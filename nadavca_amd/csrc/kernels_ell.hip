@@ -191,6 +191,17 @@ __device__ __forceinline__ X dpp_shr1(X v) {
   return X{dpp_shr1(v.m), __builtin_amdgcn_mov_dpp(v.e, 0x111, 0xf, 0xf, true)};
 }
 
+// value of lane (l - 1) mod 64 (DPP wave_ror:1, GFX9): the sweeps' hand-over at skew 1
+__device__ __forceinline__ double dpp_ror1(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, 0x13C, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_mov_dpp(hi, 0x13C, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ X dpp_ror1(X v) {
+  return X{dpp_ror1(v.m), __builtin_amdgcn_mov_dpp(v.e, 0x13C, 0xf, 0xf, false)};
+}
+
 __device__ __forceinline__ X density(double x, double mean, double ac2, double mc2) {
   double d = x - mean;
   return xm::from_log2(ac2 - d * d * mc2);  // kmer_model.cpp:48-50, in base-2 logs
@@ -395,7 +406,11 @@ __device__ __forceinline__ void load_lane_block(SweepLane *tab, const FusedParam
   }
 }
 
-template <int MEL>
+// SK1: the read's skew is 1 (every config-2-shaped read: a lane is done with its row before the row 64 further
+// on begins) — the left neighbour's values of ONE step ago are one DPP wave rotate away, and the history rings in
+// LDS, their six accesses per step and the wave barrier between a step's write and the next step's read are not
+// needed.  Other skews keep the rings.
+template <int MEL, bool SK1>
 __device__ void sweep_fast(const FusedParam *desc, int R, int N, int c, const double *sig, bool mirror,
                            double *ring, int RM, SweepLane *tab, const double *etab, double *hist_m,
                            double *hist_g, int *hist_e, int H, double *st_m, int32_t *st_e, int lane) {
@@ -440,6 +455,7 @@ __device__ void sweep_fast(const FusedParam *desc, int R, int N, int c, const do
   };
   fill(t_min);
   int su = 0, sr = ((-c) % H + H) % H;
+  X pe = xm::zero(), pg = xm::one();  // SK1: this lane's emitting value and density of the previous step
   for (int u = 0; u < n_steps; ++u) {
     const int t = t_min + u;
     bool fin = (i > d.ebe) && (j < R);
@@ -466,11 +482,17 @@ __device__ void sweep_fast(const FusedParam *desc, int R, int N, int c, const do
       for (int k = 0; k <= MEL; k++) st.wq[k] = xm::norm(st.wq[k]);
     }
     const double x = ring[(i - 1) & RM];
-    const int hs = sr * 64 + ((lane - 1) & 63);
     // left neighbour, c steps ago, same cell: its emitting value (zero beyond its last cell; only
     // taken from the wobble row's first cell on) and its density
-    X pred{hist_m[hs], hist_e[2 * hs]};
-    const X ga{hist_g[hs], hist_e[2 * hs + 1]};
+    X pred, ga;
+    if (SK1) {
+      pred = dpp_ror1(pe);
+      ga = dpp_ror1(pg);
+    } else {
+      const int hs = sr * 64 + ((lane - 1) & 63);
+      pred = X{hist_m[hs], hist_e[2 * hs]};
+      ga = X{hist_g[hs], hist_e[2 * hs + 1]};
+    }
     if (j == 0) pred = xm::one();  // prefix[0] / suffix[R]: all ones on their band
     const X gb = density_x(x, d.bm, d.bac, d.bmc, etab);
     // The emitting value is handed from lane to lane R times: it is normalised on EVERY step.  A value
@@ -480,19 +502,26 @@ __device__ void sweep_fast(const FusedParam *desc, int R, int N, int c, const do
     (void)fused_step_fast<MEL>(d, st, i, gb, ga, pred, xm::zero());
     st.em = xm::norm(st.em);
     const X en = st.em;
-    const int hw = su * 64 + lane;
-    hist_m[hw] = en.m;
-    hist_g[hw] = gb.m;
-    *reinterpret_cast<int2 *>(hist_e + 2 * hw) = make_int2(en.e, gb.e);
+    if (SK1) {
+      pe = en;
+      pg = gb;
+    } else {
+      const int hw = su * 64 + lane;
+      hist_m[hw] = en.m;
+      hist_g[hw] = gb.m;
+      *reinterpret_cast<int2 *>(hist_e + 2 * hw) = make_int2(en.e, gb.e);
+    }
     if (i >= ebs && i <= d.ebe) {  // row-major store, un-mirrored cell index
       int off = soff + (mirror ? (d.ebe - i) : (i - ebs));
       st_m[off] = en.m;
       st_e[off] = en.e;
     }
     i += 1;
-    su = (su + 1 == H) ? 0 : su + 1;
-    sr = (sr + 1 == H) ? 0 : sr + 1;
-    WAVE_SYNC();
+    if (!SK1) {
+      su = (su + 1 == H) ? 0 : su + 1;
+      sr = (sr + 1 == H) ? 0 : sr + 1;
+      WAVE_SYNC();
+    }
   }
 }
 
@@ -572,11 +601,19 @@ __global__ __launch_bounds__(64, 3) void ell_kernel(EllArgs g) {
     if (NVK_ELL_ABL == 2) {
     } else if (FAST) {
       SweepLane *ltab = reinterpret_cast<SweepLane *>(tab);  // same window, smaller entries
-      sweep_fast<MEL>(g.pl.fwd + m.row_off, R, N, c, sig, false, ring, RM, ltab, etab, hist_m, hist_g,
-                      hist_e, g.H, pre_m, pre_e, lane);
-      __syncthreads();
-      sweep_fast<MEL>(g.pl.rev + m.row_off, R, N, c, sig, true, ring, RM, ltab, etab, hist_m, hist_g,
-                      hist_e, g.H, suf_m, suf_e, lane);
+      if (c == 1) {
+        sweep_fast<MEL, true>(g.pl.fwd + m.row_off, R, N, c, sig, false, ring, RM, ltab, etab, hist_m, hist_g,
+                              hist_e, g.H, pre_m, pre_e, lane);
+        __syncthreads();
+        sweep_fast<MEL, true>(g.pl.rev + m.row_off, R, N, c, sig, true, ring, RM, ltab, etab, hist_m, hist_g,
+                              hist_e, g.H, suf_m, suf_e, lane);
+      } else {
+        sweep_fast<MEL, false>(g.pl.fwd + m.row_off, R, N, c, sig, false, ring, RM, ltab, etab, hist_m, hist_g,
+                               hist_e, g.H, pre_m, pre_e, lane);
+        __syncthreads();
+        sweep_fast<MEL, false>(g.pl.rev + m.row_off, R, N, c, sig, true, ring, RM, ltab, etab, hist_m, hist_g,
+                               hist_e, g.H, suf_m, suf_e, lane);
+      }
     } else {
       sweep<MEL>(g.pl.fwd + m.row_off, R, N, c, sig, false, ring, RM, tab, hist_m, hist_e, g.H, pre_m,
                  pre_e, lane);

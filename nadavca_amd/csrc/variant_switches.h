@@ -20,12 +20,18 @@
 #ifndef NVK_TWO_PHASE
 #define NVK_TWO_PHASE 1    // 0: the one-launch form (both sweeps of a read in one wave)
 #endif
+#ifndef NVK_SLOTS_F
+#define NVK_SLOTS_F 0      // kernels_align3.hip launcher: persistent workgroups of the forward / reverse launch
+#endif
+#ifndef NVK_SLOTS_R
+#define NVK_SLOTS_R 0
+#endif
 #ifndef NVK_ELL_ABL
 #define NVK_ELL_ABL 0      // kernels_ell.hip, timing only: 1 no hypothesis phase, 2 no sweeps
 #endif
 
 #if !defined(NVK_VARIANT_BUILD) &&                                                                            \
     (NVK_ABL != 0 || NVK_NO_TIEFLAG != 0 || NVK_PAIR_DEBUG != 0 || NVK_NO_PAIR != 0 || NVK_TWO_PHASE != 1 || \
-     NVK_ELL_ABL != 0 || defined(NVK_FLAG_DEBUG) || defined(NVK_DEBUG_SWITCHES))
+     NVK_ELL_ABL != 0 || NVK_SLOTS_F != 0 || NVK_SLOTS_R != 0 || defined(NVK_FLAG_DEBUG) || defined(NVK_DEBUG_SWITCHES))
 #error "a development switch is set in a product build (variant_switches.h): use tools/build_variant.sh"
 #endif
