@@ -103,7 +103,7 @@ def align_signal_batch(reference_filename, read_batch, config=defaults.CONFIG_FI
     import numpy
     import torch
     from . import readbatch
-    from .device import DeviceBatch, normalize_groups_dev, refine_renorm_loop_dev
+    from .device import DeviceBatch, normalize_groups_dev, refine_renorm_loop_dev, to_host
     config = _load_config(config)
     if isinstance(kmer_model, str):
         kmer_model = KmerModel.load_from_hdf5(kmer_model)
@@ -153,5 +153,5 @@ def align_signal_batch(reference_filename, read_batch, config=defaults.CONFIG_FI
     rows[:, 1] = events[:, 0] + start
     rows[:, 2] = events[:, 1] + start
     rb.normalized = norm
-    return AlignedBatch(sa.live.cpu().numpy(), status.cpu().numpy(), rows.cpu().numpy(), sa.ref_off.cpu().numpy(),
+    return AlignedBatch(sa.live.cpu().numpy(), status.cpu().numpy(), to_host(rows), sa.ref_off.cpu().numpy(),
                         sa, [f.cpu().numpy() for f in fits], norm, rb.sig_off)

@@ -300,46 +300,43 @@ __global__ void event_means_kernel(int64_t n_reads, int64_t total_ref, const dou
   out[g] = m;
 }
 
-// one block per read: least squares of y (event means) on x (expected levels), then the rescale of
-// the read's samples.  Thread 0 takes the sums (R is a few hundred to a few thousand values).
-__global__ __launch_bounds__(NT) void linfit_rescale_kernel(int64_t n_reads, const double *expected,
-                                                           const double *means, const int64_t *ref_off,
-                                                           const int32_t *status, double *signal,
-                                                           const int64_t *sig_off, double *out_fit) {
-  __shared__ double sh_fit[2];
+// Least squares of y (event means) on x (expected levels) per read, then the rescale of the read's samples.
+// The sums keep numpy's order (pairwise for the two means, index order for the centred products), so they are a
+// serial chain per read: ONE THREAD per read takes them (10 000 chains side by side instead of one per block with
+// 255 threads waiting: 3.1 -> 0.4 ms per 10 000 reads), a second launch rescales the samples with every thread.
+__global__ __launch_bounds__(64) void linfit_kernel(int64_t n_reads, const double *expected, const double *means,
+                                                    const int64_t *ref_off, const int32_t *status,
+                                                    double *fit) {
+  const int64_t rd = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (rd >= n_reads) return;
+  const int64_t r0 = ref_off[rd], R = ref_off[rd + 1] - r0;
+  double slope = nan(""), icpt = nan("");
+  if ((!status || status[rd] == 0) && R > 0) {
+    const double *x = expected + r0, *y = means + r0;
+    const double xm = np_sum(x, R) / (double)R;
+    const double ym = np_sum(y, R) / (double)R;
+    double sxx = 0.0, sxy = 0.0;
+    for (int64_t i = 0; i < R; i++) {
+      const double dx = x[i] - xm, dy = y[i] - ym;
+      sxx += dx * dx;
+      sxy += dx * dy;
+    }
+    const double f = 1.0 / (double)R;  // numpy.cov(bias=1) multiplies by the reciprocal
+    slope = (sxy * f) / (sxx * f);
+    icpt = ym - slope * xm;
+  }
+  fit[2 * rd] = slope;
+  fit[2 * rd + 1] = icpt;
+}
+
+__global__ __launch_bounds__(NT) void rescale_kernel(int64_t n_reads, const double *fit, const int64_t *ref_off,
+                                                     const int32_t *status, double *signal,
+                                                     const int64_t *sig_off) {
   for (int64_t rd = blockIdx.x; rd < n_reads; rd += gridDim.x) {
-    const int64_t r0 = ref_off[rd], R = ref_off[rd + 1] - r0;
-    const bool live = (!status || status[rd] == 0) && R > 0;
-    if (threadIdx.x == 0) {
-      double slope = nan(""), icpt = nan("");
-      if (live) {
-        const double *x = expected + r0, *y = means + r0;
-        const double xm = np_sum(x, R) / (double)R;
-        const double ym = np_sum(y, R) / (double)R;
-        double sxx = 0.0, sxy = 0.0;
-        for (int64_t i = 0; i < R; i++) {
-          const double dx = x[i] - xm, dy = y[i] - ym;
-          sxx += dx * dx;
-          sxy += dx * dy;
-        }
-        const double f = 1.0 / (double)R;  // numpy.cov(bias=1) multiplies by the reciprocal
-        slope = (sxy * f) / (sxx * f);
-        icpt = ym - slope * xm;
-      }
-      sh_fit[0] = slope;
-      sh_fit[1] = icpt;
-      if (out_fit) {
-        out_fit[2 * rd] = slope;
-        out_fit[2 * rd + 1] = icpt;
-      }
-    }
-    __syncthreads();
-    if (live) {
-      const double slope = sh_fit[0], icpt = sh_fit[1];
-      const int64_t s0 = sig_off[rd], N = sig_off[rd + 1] - s0;
-      for (int64_t i = threadIdx.x; i < N; i += NT) signal[s0 + i] = (signal[s0 + i] - icpt) / slope;
-    }
-    __syncthreads();
+    if ((status && status[rd] != 0) || ref_off[rd + 1] <= ref_off[rd]) continue;
+    const double slope = fit[2 * rd], icpt = fit[2 * rd + 1];
+    const int64_t s0 = sig_off[rd], N = sig_off[rd + 1] - s0;
+    for (int64_t i = threadIdx.x; i < N; i += NT) signal[s0 + i] = (signal[s0 + i] - icpt) / slope;
   }
 }
 
@@ -556,11 +553,18 @@ extern "C" int nvk_linfit_rescale_dev(nvk_ctx *ctx, int64_t n_reads, const doubl
   }
   if (n_reads == 0) return NVK_OK;
   NVK_HIP(hipSetDevice(ctx->device));
+  if (!out_fit) {
+    int rc = nvk_ws_reserve(ctx, WS_BANDTMP, (size_t)(2 * n_reads) * sizeof(double));
+    if (rc) return rc;
+    out_fit = (double *)ctx->ws[WS_BANDTMP];
+  }
   {
     TimerScope ts(ctx, NVK_K_RENORM);
+    hipLaunchKernelGGL(linfit_kernel, dim3((unsigned)((n_reads + 63) / 64)), dim3(64), 0, ctx->stream, n_reads,
+                       expected, means, ref_off, status, out_fit);
     const unsigned blocks = (unsigned)(n_reads < 65535 * 16 ? n_reads : 65535 * 16);
-    hipLaunchKernelGGL(linfit_rescale_kernel, dim3(blocks), dim3(NT), 0, ctx->stream, n_reads, expected,
-                       means, ref_off, status, signal, sig_off, out_fit);
+    hipLaunchKernelGGL(rescale_kernel, dim3(blocks), dim3(NT), 0, ctx->stream, n_reads, (const double *)out_fit,
+                       ref_off, status, signal, sig_off);
   }
   NVK_HIP(hipGetLastError());
   NVK_HIP(hipStreamSynchronize(ctx->stream));

@@ -1,5 +1,6 @@
-"""Where the time of ``estimate_snps_batch`` goes: the bench's api_estimate_snps workload (10 000 reads on a 10 kb
-reference) with every device stage wrapped in a synchronised wall clock.  `python tools/snps_stages.py [N]`."""
+"""Where the time of ``estimate_snps_batch`` / ``align_signal_batch`` goes: the bench's api_* workloads (10 000 reads
+on a 10 kb reference) with every device stage wrapped in a synchronised wall clock.
+`python tools/snps_stages.py [N] [snps|align]`."""
 import sys
 import time
 import collections
@@ -13,6 +14,7 @@ ES = sys.modules['nadavca_amd.estimate_snps']
 from nadavca_amd.align_signal import _load_config
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+what = sys.argv[2] if len(sys.argv) > 2 else 'snps'
 model = synthetic.load_model_arrays()
 ctx = _lib.default_context()
 km = dtw.KmerModel(*model, context=ctx)
@@ -35,7 +37,8 @@ def wrap(mod, name):
 
 
 for nm in ('normalize_groups_dev', 'refine_alignment_dev', 'expected_levels_dev', 'event_means_dev', 'spline_fit_dev',
-           'splev_groups_dev', 'estimate_log_likelihoods_dev', 'consensus_accumulate_dev', 'posterior_segments_dev'):
+           'splev_groups_dev', 'estimate_log_likelihoods_dev', 'consensus_accumulate_dev', 'posterior_segments_dev',
+           'refine_renorm_loop_dev', 'linfit_rescale_dev', 'to_host'):
     wrap(device, nm)
 wrap(readbatch, 'signal_alignments')
 wrap(device.DeviceBatch, 'from_windows')
@@ -43,7 +46,11 @@ for it in range(3):
     acc.clear()
     torch.cuda.synchronize()
     t = time.perf_counter()
-    ES.estimate_snps_batch(genome, rb, config=cfg, kmer_model=km, aligner=aligner)
+    if what == 'snps':
+        ES.estimate_snps_batch(genome, rb, config=cfg, kmer_model=km, aligner=aligner)
+    else:
+        from nadavca_amd.align_signal import align_signal_batch
+        align_signal_batch(None, rb, kmer_model=km, aligner=aligner)
     torch.cuda.synchronize()
     tot = time.perf_counter() - t
 print('total %.1f ms (%.0f reads/s)' % (tot * 1e3, n / tot))
