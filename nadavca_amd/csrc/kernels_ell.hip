@@ -70,12 +70,28 @@ constexpr int HRS = 16;    // fast phase C: steps between mantissa normalisation
     __builtin_amdgcn_wave_barrier();                       \
   } while (0)
 
+// One cell of the row store: 16 bytes, one store / one load (round 3; before: 8 + 4 bytes in two arrays — two
+// accesses per cell, and twice as many partly written lines open per wave than the L2 holds: the HBM write traffic
+// was 2.7 x the cells).
+struct __attribute__((aligned(16))) Cell {
+  double m;
+  int32_t e;
+  int32_t pad;
+};
+__device__ __forceinline__ void cell_put(Cell *p, X v) {
+  *reinterpret_cast<int4 *>(p) = make_int4(__double2loint(v.m), __double2hiint(v.m), v.e, 0);
+}
+typedef int v3i_t __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ X cell_get(const Cell *p) {
+  const v3i_t r = *reinterpret_cast<const v3i_t *>(p);  // 12 of the 16 bytes: no register for the padding
+  return X{__hiloint2double(r.y, r.x), r.z};
+}
+
 struct EllArgs {
   DeviceModel dm;
   BatchArgs a;
   EllPlan pl;
-  double *store_m;  // row store mantissas: [slot][2][cells]  (prefix rows, then suffix rows)
-  int32_t *store_e;
+  Cell *store;  // row store: [slot][2][cells]  (prefix rows, then suffix rows)
   int64_t store_stride;  // cells per slot (both halves)
   int64_t half;          // cells per half
   int n_reads;
@@ -299,7 +315,7 @@ __device__ __forceinline__ int64_t kmer_id_mod(const DeviceModel &dm, const int3
 template <int MEL>
 __device__ void sweep(const FusedParam *desc, int R, int N, int c, const double *sig, bool mirror,
                       double *ring, int RM, FusedParam *tab, double *hist_m, int *hist_e, int H,
-                      double *st_m, int32_t *st_e, int lane) {
+                      Cell *rows_out, int lane) {
   // the predecessor of position 0 is the all-ones row on its band (prefix[0] / suffix[R])
   int r_old = 0, loaded_hi = 0;
   load_tab_block(tab, desc, 0, R, lane);
@@ -371,8 +387,7 @@ __device__ void sweep(const FusedParam *desc, int R, int N, int c, const double 
     hist_e[su * 64 + lane] = en.e;
     if (on && i >= ebs) {  // row-major store, un-mirrored cell index
       int off = soff + (mirror ? (d.ebe - i) : (i - ebs));
-      st_m[off] = en.m;
-      st_e[off] = en.e;
+      cell_put(rows_out + off, en);
     }
     i += 1;
     su = (su + 1 == H) ? 0 : su + 1;
@@ -413,7 +428,7 @@ __device__ __forceinline__ void load_lane_block(SweepLane *tab, const FusedParam
 template <int MEL, bool SK1>
 __device__ void sweep_fast(const FusedParam *desc, int R, int N, int c, const double *sig, bool mirror,
                            double *ring, int RM, SweepLane *tab, const double *etab, double *hist_m,
-                           double *hist_g, int *hist_e, int H, double *st_m, int32_t *st_e, int lane) {
+                           double *hist_g, int *hist_e, int H, Cell *rows_out, int lane) {
   int r_old = 0, loaded_hi = 0;
   load_lane_block(tab, desc, 0, R, lane);
   __syncthreads();
@@ -513,8 +528,7 @@ __device__ void sweep_fast(const FusedParam *desc, int R, int N, int c, const do
     }
     if (i >= ebs && i <= d.ebe) {  // row-major store, un-mirrored cell index
       int off = soff + (mirror ? (d.ebe - i) : (i - ebs));
-      st_m[off] = en.m;
-      st_e[off] = en.e;
+      cell_put(rows_out + off, en);
     }
     i += 1;
     if (!SK1) {
@@ -541,15 +555,12 @@ __global__ __launch_bounds__(64, 3) void ell_kernel(EllArgs g) {
   const int RM = g.SR - 1;
   const DeviceModel dm = g.dm;
   const int alpha = dm.alphabet;
-  double *pre_m = g.store_m + (size_t)blockIdx.x * g.store_stride;
-  int32_t *pre_e = g.store_e + (size_t)blockIdx.x * g.store_stride;
-  double *suf_m = pre_m + g.half;
-  int32_t *suf_e = pre_e + g.half;
+  Cell *pre = g.store + (size_t)blockIdx.x * g.store_stride;
+  Cell *suf = pre + g.half;
   for (int q = lane; q < g.SR; q += 64) ring[q] = 0.0;
   dens::fill_table(etab, lane, 64);
   if (lane == 0) {  // the store's last cell is never part of a row: a zero the streams can point at
-    pre_m[g.store_stride - 1] = 0.0;
-    pre_e[g.store_stride - 1] = xm::XZ;
+    cell_put(pre + g.store_stride - 1, xm::zero());
   }
 
   while (true) {
@@ -590,12 +601,10 @@ __global__ __launch_bounds__(64, 3) void ell_kernel(EllArgs g) {
 
     // rows that are all ones: prefix[0] on band 0, suffix[R] on band R (dtw.cpp:50,66-67)
     for (int x = bs[0] + lane; x <= be[0]; x += 64) {
-      pre_m[rowoff[0] + x - bs[0]] = 0.5;
-      pre_e[rowoff[0] + x - bs[0]] = 1;
+      cell_put(pre + rowoff[0] + x - bs[0], xm::one());
     }
     for (int x = bs[R] + lane; x <= be[R]; x += 64) {
-      suf_m[rowoff[R] + x - bs[R]] = 0.5;
-      suf_e[rowoff[R] + x - bs[R]] = 1;
+      cell_put(suf + rowoff[R] + x - bs[R], xm::one());
     }
     // ---- A, B: the two sweeps
     if (NVK_ELL_ABL == 2) {
@@ -603,23 +612,21 @@ __global__ __launch_bounds__(64, 3) void ell_kernel(EllArgs g) {
       SweepLane *ltab = reinterpret_cast<SweepLane *>(tab);  // same window, smaller entries
       if (c == 1) {
         sweep_fast<MEL, true>(g.pl.fwd + m.row_off, R, N, c, sig, false, ring, RM, ltab, etab, hist_m, hist_g,
-                              hist_e, g.H, pre_m, pre_e, lane);
+                              hist_e, g.H, pre, lane);
         __syncthreads();
         sweep_fast<MEL, true>(g.pl.rev + m.row_off, R, N, c, sig, true, ring, RM, ltab, etab, hist_m, hist_g,
-                              hist_e, g.H, suf_m, suf_e, lane);
+                              hist_e, g.H, suf, lane);
       } else {
         sweep_fast<MEL, false>(g.pl.fwd + m.row_off, R, N, c, sig, false, ring, RM, ltab, etab, hist_m, hist_g,
-                               hist_e, g.H, pre_m, pre_e, lane);
+                               hist_e, g.H, pre, lane);
         __syncthreads();
         sweep_fast<MEL, false>(g.pl.rev + m.row_off, R, N, c, sig, true, ring, RM, ltab, etab, hist_m, hist_g,
-                               hist_e, g.H, suf_m, suf_e, lane);
+                               hist_e, g.H, suf, lane);
       }
     } else {
-      sweep<MEL>(g.pl.fwd + m.row_off, R, N, c, sig, false, ring, RM, tab, hist_m, hist_e, g.H, pre_m,
-                 pre_e, lane);
+      sweep<MEL>(g.pl.fwd + m.row_off, R, N, c, sig, false, ring, RM, tab, hist_m, hist_e, g.H, pre, lane);
       __syncthreads();
-      sweep<MEL>(g.pl.rev + m.row_off, R, N, c, sig, true, ring, RM, tab, hist_m, hist_e, g.H, suf_m,
-                 suf_e, lane);
+      sweep<MEL>(g.pl.rev + m.row_off, R, N, c, sig, true, ring, RM, tab, hist_m, hist_e, g.H, suf, lane);
     }
     __syncthreads();
 
@@ -627,7 +634,7 @@ __global__ __launch_bounds__(64, 3) void ell_kernel(EllArgs g) {
     X tot = xm::zero();
     for (int x = bs[R] + lane; x <= be[R]; x += 64) {
       int o = rowoff[R] + x - bs[R];
-      X v = xm::mul(X{pre_m[o], pre_e[o]}, X{suf_m[o], suf_e[o]});
+      X v = xm::mul(cell_get(pre + o), cell_get(suf + o));
       tot = xm::add_norm(tot, v);
     }
     for (int dlt = 32; dlt >= 1; dlt >>= 1) {
@@ -665,7 +672,7 @@ __global__ __launch_bounds__(64, 3) void ell_kernel(EllArgs g) {
         HypDesc d;
         d.wbs = 0x40000000; d.wbe = -0x40000000; d.elo = 0x40000000; d.ebe = -0x40000000;
         d.has_wob = 0; d.bm = 0.0; d.bac = 0.0; d.bmc = 0.0;
-        // input stream of the lane: cell i lives at pre_m/pre_e[sbase + i] (the suffix rows follow the
+        // input stream of the lane: cell i lives at pre[sbase + i] (the suffix rows follow the
         // prefix rows in the same store, g.half cells on), valid for i in [slo, shi]; every other cell
         // reads the store's zero cell
         int sbase = 0, slo = 0x40000000, shi = -0x40000000;
@@ -712,7 +719,12 @@ __global__ __launch_bounds__(64, 3) void ell_kernel(EllArgs g) {
         steps = __builtin_amdgcn_readfirstlane(steps);  // uniform trip count
         const int i0 = base - gl;
         // clamped, unsigned element offsets from uniform base pointers (scalar base + 32-bit offset)
-        auto sidx = [&](int i) { return (unsigned)((i >= slo && i <= shi) ? sbase + i : smax); };
+        // byte offset of the stream's cell i from the slot's (scalar) base; the store's zero cell outside the band
+        const int sb16 = 16 * sbase;
+        auto sload = [&](int i) {
+          const unsigned off = (unsigned)((i >= slo && i <= shi) ? sb16 + 16 * i : 16 * smax);
+          return cell_get(reinterpret_cast<const Cell *>(reinterpret_cast<const char *>(pre) + off));
+        };
         // sample s[i-1] of cell i, clamped into the read (cells beyond it are outside every band): a byte offset
         // from the read's uniform base pointer, one v_med3 per load
         const int xhi = 8 * (N - 1);
@@ -724,13 +736,12 @@ __global__ __launch_bounds__(64, 3) void ell_kernel(EllArgs g) {
         LaneState<MEL> st;
         st.reset();
         X acc = xm::zero(), gb_last = xm::one();
-        double cx[PF], cm[PF];
-        int ce[PF];
+        double cx[PF];
+        X cs[PF];
 #pragma unroll
         for (int q = 0; q < PF; q++) {
           cx[q] = xload(i0 + q);
-          cm[q] = pre_m[sidx(i0 + q)];
-          ce[q] = pre_e[sidx(i0 + q)];
+          cs[q] = sload(i0 + q);
         }
         // a trip = lcm(PF, MEL + 1) steps, unrolled: prefetch slot and history slot of every step are constants.
         // The steps are rounded up to whole trips (the extra cells lie beyond every band: zeros, zero cell).
@@ -746,7 +757,7 @@ __global__ __launch_bounds__(64, 3) void ell_kernel(EllArgs g) {
             const int q = w % PF, r = w % M;
             const int u = ub + w;
             const int i = i0 + u;
-            const X sv{cm[q], ce[q]};  // zero outside the stream's band (zero cell)
+            const X sv = cs[q];  // zero outside the stream's band (zero cell)
             const X ga = dpp_shr1(gb_last);
             // the emitting row of the lane to the left, one step ago: zero beyond its last cell, and only taken
             // from the wobble row's first cell on; for the first position that lane is role 0, which hands
@@ -762,8 +773,7 @@ __global__ __launch_bounds__(64, 3) void ell_kernel(EllArgs g) {
             // node.cpp:31-37; only the closing lane's total is used (the other lanes sum garbage)
             acc = add_lazy(acc, xm::mul(st.wq[RING ? r : 0], sv));
             cx[q] = xload(i0 + u + PF);
-            cm[q] = pre_m[sidx(i0 + u + PF)];
-            ce[q] = pre_e[sidx(i0 + u + PF)];
+            cs[q] = sload(i0 + u + PF);
           }
           if ((ub + TRIP) % NRM == 0) {  // keep the lazily summed mantissas near 1
 #pragma unroll
@@ -795,8 +805,7 @@ __global__ __launch_bounds__(64, 3) void ell_kernel(EllArgs g) {
       d.has_wob = 0; d.am = d.aac2 = d.amc2 = d.bm = d.bac2 = d.bmc2 = 0.0;
       // input stream of the lane: prefix[first] for the group's first lane, suffix[last+1] for
       // the closing lane; index of cell i in the row store = sbase + i, valid for i in [slo, shi]
-      const double *sm = pre_m;
-      const int32_t *se = pre_e;
+      const Cell *sc = pre;
       int sbase = 0, slo = 0x40000000, shi = -0x40000000;
       if (is_pos) {
         const int j = first + gl;
@@ -828,7 +837,7 @@ __global__ __launch_bounds__(64, 3) void ell_kernel(EllArgs g) {
         }
         d.pbs = bs[last + 1]; d.pbe = be[last + 1];
         d.ebe = d.wbe;
-        sm = suf_m; se = suf_e;
+        sc = suf;
         sbase = rowoff[last + 1] - bs[last + 1];
         slo = bs[last + 1]; shi = be[last + 1];
       }
@@ -850,16 +859,14 @@ __global__ __launch_bounds__(64, 3) void ell_kernel(EllArgs g) {
 #pragma unroll
       for (int q = 0; q < PF; q++) {
         cx[q] = sig[xidx(i0 + q)];
-        cm[q] = sm[sidx(i0 + q)];
-        ce[q] = se[sidx(i0 + q)];
+        { const X v = cell_get(sc + sidx(i0 + q)); cm[q] = v.m; ce[q] = v.e; }
       }
       __syncthreads();
       for (int ub = 0; ub < steps; ub += PF) {
 #pragma unroll
         for (int q = 0; q < PF; q++) {
           nx[q] = sig[xidx(i0 + ub + PF + q)];
-          nm[q] = sm[sidx(i0 + ub + PF + q)];
-          ne[q] = se[sidx(i0 + ub + PF + q)];
+          { const X v = cell_get(sc + sidx(i0 + ub + PF + q)); nm[q] = v.m; ne[q] = v.e; }
         }
 #pragma unroll
         for (int q = 0; q < PF; q++) {
@@ -940,10 +947,8 @@ int launch_ell(nvk_ctx *ctx, const DeviceModel &dm, const BatchArgs &a, int wobb
   const int64_t half = (int64_t)(tot.max_W > 0 ? tot.max_W : 1) + 64;
   const int64_t stride = 2 * half;
   const int64_t cap = nvk_spill_cap(ctx, WS_SPILL);
-  while (slots > 1 && slots * stride * 12 > cap) slots /= 2;
-  int rc = nvk_ws_reserve(ctx, WS_SPILL, (size_t)slots * stride * 8);
-  if (rc) return rc;
-  rc = nvk_ws_reserve(ctx, WS_STAGE, (size_t)slots * stride * 4);
+  while (slots > 1 && slots * stride * (int64_t)sizeof(Cell) > cap) slots /= 2;
+  int rc = nvk_ws_reserve(ctx, WS_SPILL, (size_t)slots * stride * sizeof(Cell));
   if (rc) return rc;
   rc = nvk_ws_reserve(ctx, WS_MISC, 256);
   if (rc) return rc;
@@ -954,8 +959,7 @@ int launch_ell(nvk_ctx *ctx, const DeviceModel &dm, const BatchArgs &a, int wobb
   g.dm = dm;
   g.a = a;
   g.pl = pl;
-  g.store_m = (double *)ctx->ws[WS_SPILL];
-  g.store_e = (int32_t *)ctx->ws[WS_STAGE];
+  g.store = (Cell *)ctx->ws[WS_SPILL];
   g.store_stride = stride;
   g.half = half;
   g.n_reads = (int)a.n_reads;
