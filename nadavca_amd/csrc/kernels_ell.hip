@@ -173,7 +173,11 @@ __device__ __forceinline__ void fused_step_ring(const HypDesc &d, LaneState<MEL>
   mix.m = mix.m * d.wmul;
   mix.e = mix.e + d.wexp;
   X wn = add_lazy(pred, xm::mul(mix, st.wq[(r + M - 1) % M]));
+#if NVK_ELL_EMASK
+  wn.e = (i >= d.wbs && i <= d.wbe) ? wn.e : xm::XZ;
+#else
   wn = xm::sel(i >= d.wbs && i <= d.wbe, wn, xm::zero());
+#endif
   st.wq[r] = wn;  // replaces the value of step u - M; the one of step u - MEL is wq[(r + 1) % M]
   X en;
   if (MEL >= 1) {
@@ -782,7 +786,13 @@ __global__ __launch_bounds__(64, 3) void ell_kernel(EllArgs g) {
             acc = xm::norm(acc);
           }
         }
-        if (is_fin) out[(size_t)p * alpha + b] = xm::to_log(xm::norm(acc));
+        if (is_fin) {
+          acc = xm::norm(acc);
+#if NVK_ELL_EMASK
+          if (acc.e < xm::XZ / 2) acc = xm::zero();  // made of nothing but out-of-band values
+#endif
+          out[(size_t)p * alpha + b] = xm::to_log(acc);
+        }
       }
     } else {
     for (int b0 = 0; b0 < n_items; b0 += 64 / GL) {
