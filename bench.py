@@ -42,11 +42,16 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-# vector-instruction issue peak: one wave64 VALU instruction per 4 cycles and SIMD at the 2.4 GHz maximum clock
-# (MI355X_MICROARCH.md), 1024 SIMDs x 64 lanes.  (tools/ubench_valu.hip measures 2.24 ns = ~5 cycles for
-# back-to-back dependent-free v_fma_f64 — the kernel's mix holds cheaper instructions too, so the 4-cycle
-# bound is the one no mix can exceed.)
-VALU_PEAK_TLANE = 1024 * 64 * 2.4e9 / 4 / 1e12
+# vector-instruction issue peak at the 2.4 GHz maximum clock (MI355X_MICROARCH.md), 1024 SIMDs x 64 lanes:
+# Issue bound of the log-likelihood kernel's instruction mix.  A wave64 FP64 instruction (and the 32-bit compares,
+# selects, max / shift-add forms) occupies its SIMD for 4 cycles, the plain 32-bit integer ones (v_add_u32,
+# v_sub_u32, v_and_b32, v_mov_b32 incl. its DPP form) for 2 (profiles/ubench_valu_gfx950.txt: 1.06-1.14 ns against
+# 1.85-2.3 ns per wave-instruction).  The hypothesis loop, 5/6 of the kernel's instructions, holds 266 of the
+# second kind among its 905 per 12-step trip (hipcc -S listing of kernels_ell.hip, tools/isa_blocks.py): 3.41
+# cycles per instruction on average.  (Rounds 1-2 used 4 cycles for every instruction; the kernel now runs close
+# enough to the bound for the difference to show: that figure would read 1.04 on 200 000 reads.)
+VALU_CYCLES_PER_INST = (639 * 4 + 266 * 2) / 905.0
+VALU_PEAK_TLANE = 1024 * 64 * 2.4e9 / VALU_CYCLES_PER_INST / 1e12
 
 
 def cpu_baseline(batch, model, bandwidth, mel, workload, budget_reads_per_core=256):
@@ -361,8 +366,9 @@ def main():
             algo = dbatch.algorithmic_bytes_snp(stats['band_cells'])
             rl = {'bound': 'valu', 'kernel': kname, 'unit': 'Tlane-inst/s', 'peak': VALU_PEAK_TLANE,
                   'note': 'vector lane-instructions per second, in units of 1e12 (an FMA counts once, so these '
-                          'are not flops); peak = 1 wave64 instruction / 4 cycles / SIMD at 2.4 GHz x 1024 SIMDs '
-                          'x 64 lanes', 'from_profile': src,
+                          'are not flops); peak = 1 wave64 instruction / %.2f cycles (4 for FP64 and compare / select '
+                          'forms, 2 for plain 32-bit integer ones, weighted by the hypothesis loop\'s mix) / SIMD at '
+                          '2.4 GHz x 1024 SIMDs x 64 lanes' % VALU_CYCLES_PER_INST, 'from_profile': src,
                   'kernel_ms_per_launch': ms / launches, 'all_kernels_ms': per_kernel,
                   'traffic': traffic * n_reads if traffic else None, 'algorithmic_bytes_per_launch': algo,
                   'hbm_frac': algo / sec / 1e9 / HBM_PEAK_GBS}
