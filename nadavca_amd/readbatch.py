@@ -27,15 +27,16 @@ class ReadBatch:
     """n reads end to end.  raw_signal: any real dtype (fast5 holds int16 ADC counts), read j at
     [sig_off[j], sig_off[j+1]); sequence: base codes 0..3, read j at [seq_off[j], seq_off[j+1]); the
     basecaller's base -> sample table (``Read.sequence_to_signal_mapping``) as parallel arrays map_base /
-    map_sig, read j at [map_off[j], map_off[j+1]), bases ascending inside a read."""
+    map_sig, read j at [map_off[j], map_off[j+1]), bases ascending inside a read.  The two tables are kept as int32
+    (positions inside ONE read): they are 2 x 16 MB per 10 000 reads to carry across PCIe instead of 2 x 32."""
 
     def __init__(self, raw_signal, sig_off, sequence, seq_off, map_base, map_sig, map_off):
         self.raw_signal = np.ascontiguousarray(raw_signal)
         self.sig_off = np.ascontiguousarray(sig_off, dtype=np.int64)
         self.sequence = np.ascontiguousarray(sequence, dtype=np.int32)
         self.seq_off = np.ascontiguousarray(seq_off, dtype=np.int64)
-        self.map_base = np.ascontiguousarray(map_base, dtype=np.int64)
-        self.map_sig = np.ascontiguousarray(map_sig, dtype=np.int64)
+        self.map_base = np.ascontiguousarray(map_base, dtype=np.int32)
+        self.map_sig = np.ascontiguousarray(map_sig, dtype=np.int32)
         self.map_off = np.ascontiguousarray(map_off, dtype=np.int64)
         self.n = self.sig_off.size - 1
         self.normalized = None   # device tensor (f64, layout of raw_signal) once normalised
@@ -65,7 +66,7 @@ class BaseAlignmentBatch:
     ``reverse[j]``: the read is on the reverse strand; a read without pairs did not align."""
 
     def __init__(self, read_idx, ref_idx, off, reverse):
-        self.read_idx = np.ascontiguousarray(read_idx, dtype=np.int64)
+        self.read_idx = np.ascontiguousarray(read_idx, dtype=np.int32)   # a position inside one read
         self.ref_idx = np.ascontiguousarray(ref_idx, dtype=np.int64)
         self.off = np.ascontiguousarray(off, dtype=np.int64)
         self.reverse = np.ascontiguousarray(reverse, dtype=bool)
@@ -99,7 +100,8 @@ def signal_alignments(rb, ba, bandwidth, reference_num, k, central, device='cpu'
     want them) or on the CPU (tests).  Index plumbing only — gathers, prefix sums, comparisons."""
     import torch
     dev = torch.device(device)
-    T = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt).to(dev)
+    # (each table crosses to the device in the dtype it is kept in and is widened there)
+    T = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a)).to(dev).to(dt)
     i64 = torch.int64
     ref_num = T(reference_num, torch.int32)
     L = int(ref_num.numel())

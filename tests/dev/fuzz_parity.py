@@ -6,14 +6,15 @@ import numpy as np
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 from nadavca_amd import dtw, synthetic
 from oracle.oracle import Oracle, LongDoubleReferee
-from fuzz_cases import make_fuzz_batch, reads_of
+from fuzz_cases import make_fuzz_batch, reads_of, classify_difference
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 o = Oracle('port')
 t_end = time.time() + budget
 t_tick = time.time() + 60
-n_batches = n_reads = n_bad = n_tie = n_hp = n_ill = 0
+n_batches = n_reads = n_bad = n_tie = 0
+kinds = {}
 it = 0
 while time.time() < t_end:
     fb = make_fuzz_batch(seed0, it); it += 1
@@ -30,32 +31,17 @@ while time.time() < t_end:
                                             c['approximate_alignment'], bw, mel, mo, tr)).reshape(-1, 2)
         if np.asarray(ev).reshape(-1, 2).shape != exp.shape or not np.array_equal(np.asarray(ev).reshape(-1, 2), exp):
             n_bad += 1
-            # Who is right?  (a) the same algorithm in long double sides with the engine on every
-            # differing row: the double reference's own rounding decided; (b) every
-            # differing boundary lies between two bases with the same k-mer level (an exactly flat
-            # plateau, decided by rounding noise at any precision); (c) neither.
+            # Who is right?  tests/fuzz_cases.classify_difference (shared with the -m gpu tests): flat plateau
+            # between equal k-mer levels / the long-double reference sides with the engine / the reference changes
+            # its own answer in long double / the long-double reference itself has a tie at that base / none.
             ev2 = np.asarray(ev).reshape(-1, 2)
-            ext = np.concatenate([c['context_before'], c['reference'], c['context_after']]).astype(np.int64)
-            ids = synthetic.kmer_ids(ext, len(c['context_before']), len(c['reference']), k, central, alphabet)
-            same_level = np.concatenate([[False], model[3][ids[1:]] == model[3][ids[:-1]]])  # base j vs j-1
             rows = np.nonzero((ev2 != exp).any(axis=1))[0] if ev2.shape == exp.shape else np.array([-1])
             if ld is None:
                 ld = LongDoubleReferee(*model)
-            hp = ld.refine_alignment(c['signal'], c['reference'], c['context_before'], c['context_after'],
-                                     c['approximate_alignment'], bw, mel, tr)
-            def flat(j):  # a boundary of row j that differs and is not between equal levels?
-                return (ev2[j, 0] == exp[j, 0] or same_level[j]) and \
-                       (ev2[j, 1] == exp[j, 1] or (j + 1 < len(ids) and same_level[j + 1]))
-            by_hp = ev2.shape == exp.shape == hp.shape and all(np.array_equal(ev2[j], hp[j]) or flat(j) for j in rows)
-            # (a') weaker: on every differing row the reference's OWN answer changes with the precision it is
-            # evaluated in (ill-conditioned arg-max: three precisions, up to three answers)
-            ill = ev2.shape == exp.shape == hp.shape and all(not np.array_equal(exp[j], hp[j]) or flat(j) for j in rows)
-            only_flat = ev2.shape == exp.shape and all(flat(j) for j in rows)
-            expl = by_hp or only_flat or ill
-            n_ill += int(ill and not by_hp and not only_flat)
-            n_tie += int(expl)
-            n_hp += int(by_hp and not only_flat)
-            print('ALIGN MISMATCH', ('flat-plateau' if only_flat else ('reference-rounding' if by_hp else 'precision-decided')) if expl else 'UNEXPLAINED', 'rows', rows[:6].tolist(), 'it', it - 1, 'case', ci, 'k', k, 'central', central, 'alphabet', alphabet, 'mel', mel, 'bw', bw, 'tr', tr,
+            why = classify_difference(ev, exp, c, model, k, central, alphabet, bw, mel, tr, referee=ld)
+            kinds[why] = kinds.get(why, 0) + 1
+            n_tie += int(why != 'UNEXPLAINED')
+            print('ALIGN MISMATCH', why, 'rows', rows[:6].tolist(), 'it', it - 1, 'case', ci, 'k', k, 'central', central, 'alphabet', alphabet, 'mel', mel, 'bw', bw, 'tr', tr,
                   'R', len(c['reference']), 'N', len(c['signal']), flush=True)
     got = dtw.estimate_log_likelihoods_batch(reads, bw, mel, mg, w)
     for ci, (c, ll) in enumerate(zip(cases, got)):
@@ -70,5 +56,6 @@ while time.time() < t_end:
                   'R', len(c['reference']), 'N', len(c['signal']), flush=True)
 print('fuzz: %d batches, %d reads; %d reads differ from the double reference, %d of them explained '
       '(%d: only on flat plateaus between equal k-mer levels; %d: the long-double reference sides with the engine; '
-      '%d: the reference changes its own answer in long double)'
-      % (n_batches, n_reads, n_bad, n_tie, n_tie - n_hp - n_ill, n_hp, n_ill))
+      '%d: the reference changes its own answer in long double; %d: the long-double reference has a tie at that base)'
+      % (n_batches, n_reads, n_bad, n_tie, kinds.get('flat-plateau', 0), kinds.get('reference-rounding', 0),
+         kinds.get('precision-decided', 0), kinds.get('referee-tie', 0)))

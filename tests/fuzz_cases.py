@@ -1,5 +1,7 @@
 """Seeded random DP problems shared by tests/dev/fuzz_parity.py, tests/dev/fuzz_repro.py and the regression
 tests that pin iterations the fuzzer once failed on."""
+import os
+
 import numpy as np
 
 
@@ -60,13 +62,104 @@ def reads_of(cases):
             for c in cases]
 
 
+_NEAR_LIB = {}
+
+
+def _near_tie_lib():
+    """An instrumented long-double copy of the CPU restatement (oracle/nadavca_oracle.c), built once per process
+    in a temporary directory: every `a > b` of the path search (node.cpp:52,72,82 restated) whose two scores
+    are equal or differ — in 80-bit arithmetic — by less than the engine's tolerance zone (NVK_TIE_ULPS = 64 ulps
+    of the reference's log value: 64 * 2^-52 relative) notes its row.  Test infrastructure."""
+    if 'lib' in _NEAR_LIB:
+        return _NEAR_LIB['lib']
+    import ctypes as C
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = open(os.path.join(root, 'oracle', 'nadavca_oracle.c')).read()
+    helper = '''#include <string.h>
+int g_near_n; int g_near_row[4096];
+static void near_note(double a, double b, int r) {   /* (`double` is long double in this build) */
+  if (!(a > -1e300) || !(b > -1e300)) return;
+  double d = a - b; if (d < 0) d = -d;   /* d == 0: a tie even in 80-bit arithmetic */
+  double m = b < 0 ? -b : b;
+  if (d <= m * 64.0 * 2.220446049250313e-16 && g_near_n < 4096) g_near_row[g_near_n++] = r;
+}
+int orc_near_count(void) { return g_near_n; }
+int *orc_near_rows(void) { return g_near_row; }
+void orc_near_reset(void) { g_near_n = 0; }
+'''
+    a = '''        double pv = dp[r - 1][i - bs[r - 1]];
+        if (pv > best) {'''
+    b = '''          double pv = dp[r - 1][from - bs[r - 1]];
+          if (pv > best) {'''
+    c = '''      for (int i = bs[r]; i <= be[r]; i++)
+        if (dp[r][i - bs[r]] > best) {
+          best = dp[r][i - bs[r]];
+          best_idx = i;
+        }'''
+    assert a in s and b in s and c in s and '#include <string.h>' in s, 'oracle/nadavca_oracle.c changed: adapt the patch'
+    s = s.replace(a, a.replace('        if (pv > best) {', '        near_note(pv, best, r);\n        if (pv > best) {'))
+    s = s.replace(b, b.replace('          if (pv > best) {', '          near_note(pv, best, r);\n          if (pv > best) {'))
+    s = s.replace(c, '''      for (int i = bs[r]; i <= be[r]; i++) {
+        near_note(dp[r][i - bs[r]], best, r + 1);
+        if (dp[r][i - bs[r]] > best) {
+          best = dp[r][i - bs[r]];
+          best_idx = i;
+        }
+      }''')
+    s = s.replace('#include <string.h>', helper, 1)
+    pre = ('#include <math.h>\n#include <stdint.h>\n#include <stdlib.h>\n#include <string.h>\n#include <stdio.h>\n'
+           '#define double long double\n#define exp expl\n#define log logl\n#define sqrt sqrtl\n')
+    tmp = tempfile.mkdtemp(prefix='orc_near_')
+    src, lib = os.path.join(tmp, 'orc_near.c'), os.path.join(tmp, 'liborc_near.so')
+    open(src, 'w').write(pre + s)
+    subprocess.run(['gcc', '-O2', '-fPIC', '-std=gnu11', '-ffp-contract=off', '-Wno-unused', '-shared', '-o', lib, src,
+                    '-lm'], check=True)
+    _NEAR_LIB['lib'] = C.CDLL(lib)
+    return _NEAR_LIB['lib']
+
+
+def near_tie_bases(case, fb_model, bw, mel, tr):
+    """Bases (event rows) at which the long-double reference compares two path scores inside the engine's
+    tolerance zone on this read."""
+    import ctypes as C
+    from oracle.oracle import LongDoubleReferee
+    lib = _near_tie_lib()
+    ld = LongDoubleReferee.__new__(LongDoubleReferee)
+    ld.lib = lib
+    ld._pld = C.POINTER(C.c_longdouble)
+    lib.orc_model_create.restype = C.c_void_p
+    lib.orc_model_create.argtypes = [C.c_int, C.c_int, C.c_int, ld._pld, ld._pld, C.c_int64]
+    lib.orc_refine_alignment.restype = C.c_int
+    p_i32 = C.POINTER(C.c_int32)
+    lib.orc_refine_alignment.argtypes = [C.c_void_p, ld._pld, C.c_int64, p_i32, C.c_int64, p_i32, C.c_int64, p_i32,
+                                         C.c_int64, p_i32, C.c_int64, C.c_int, C.c_int, C.c_int, p_i32]
+    k, central, alphabet, mean, sigma = fb_model
+    mean_l = np.ascontiguousarray(mean, dtype=np.longdouble)
+    sigma_l = np.ascontiguousarray(sigma, dtype=np.longdouble)
+    ld.handle = lib.orc_model_create(int(k), int(central), int(alphabet), mean_l.ctypes.data_as(ld._pld),
+                                     sigma_l.ctypes.data_as(ld._pld), mean_l.size)
+    lib.orc_near_reset()
+    c = case
+    ld.refine_alignment(c['signal'], c['reference'], c['context_before'], c['context_after'],
+                        c['approximate_alignment'], bw, mel, tr)
+    lib.orc_near_rows.restype = C.POINTER(C.c_int)
+    n = lib.orc_near_count()
+    rows = np.array([lib.orc_near_rows()[i] for i in range(n)], dtype=np.int64)
+    return np.unique(rows // 2 if tr else rows)
+
+
 def classify_difference(ev, exp, case, fb_model, k, central, alphabet, bw, mel, tr, referee=None):
     """Why do the engine's rows ``ev`` differ from the double-precision reference's ``exp`` on this read?
     -> one of 'flat-plateau' (every differing boundary lies between two bases with the SAME k-mer level: the
     posterior is exactly flat there and any rounding decides), 'reference-rounding' (the same algorithm in 80-bit
     long double — oracle/liboracle_ld.so — sides with the engine on every differing row), 'precision-decided'
     (the reference changes its OWN answer on every differing row when computed in long double: an ill-conditioned
-    arg-max), or 'UNEXPLAINED'.  The classification tests/dev/fuzz_parity.py prints, shared with the -m gpu
+    arg-max), 'referee-tie' (reference and long double agree, and at the differing base the long-double reference
+    itself compares two path scores that are equal or closer than the engine's tolerance zone: a tie for the
+    reference at the magnitude of ITS scores, a resolvable difference for the engine — the read carries
+    NVK_TIE_ULP or NVK_TIE_NEAR), or 'UNEXPLAINED'.  The classification tests/dev/fuzz_parity.py prints, shared with the -m gpu
     tests so that a regression cannot hide behind the near-tie flag."""
     from nadavca_amd import synthetic
     from oracle.oracle import LongDoubleReferee
@@ -96,4 +189,14 @@ def classify_difference(ev, exp, case, fb_model, k, central, alphabet, bw, mel, 
         return 'reference-rounding'
     if all(not np.array_equal(exp[j], hp[j]) or flat(j) for j in rows):
         return 'precision-decided'
+    # The reference's doubles and the long doubles agree with each other and not with the engine: accepted only
+    # where the long-double reference ITSELF finds the two path scores it compares at that base (or a neighbouring
+    # one) equal, or closer than the engine's tolerance zone.  The reference adds UNNORMALISED log posteriors
+    # (node.cpp:39-50): after r rows its scores are ~ r * |ln L(read)|, 5e6 on a sharp model, where even 80-bit
+    # arithmetic resolves 1e-12 at best — it then keeps the first maximum — while the engine's scores are products
+    # of normalised posteriors, 1e3-1e4 times smaller in the exponent, and tell such cells apart.
+    near = near_tie_bases(c, fb_model, bw, mel, tr)
+    if all(flat(j) or np.array_equal(ev2[j], hp[j]) or not np.array_equal(exp[j], hp[j]) or
+           bool(np.any(np.abs(near - j) <= 1)) for j in rows):
+        return 'referee-tie'
     return 'UNEXPLAINED'

@@ -312,3 +312,32 @@ def test_tiny_posteriors_at_the_end_of_a_short_wide_band_read(dtw, oracle_port, 
     exp = oracle_port.refine_alignment(c['signal'], c['reference'], c['context_before'], c['context_after'],
                                        c['approximate_alignment'], fb['bw'], fb['mel'], mo, fb['tr'])
     assert np.array_equal(got[case], exp)
+
+
+def test_a_tie_of_the_long_double_reference_that_the_engine_resolves(dtw, oracle_port):
+    """tests/dev/fuzz_parity.py seed 20261006, iteration 8718, read 0 (sharp model, bandwidth 4, samples clipped to
+    -5): one event end differs by a sample, the double-precision and the long-double reference agree with each
+    other — and the long-double reference has an EXACT tie between the path scores it compares at that base, the
+    only such base of the read.  The reference adds unnormalised log posteriors (node.cpp:39-50): its scores are
+    ~5e6 there, where 80-bit arithmetic resolves 1e-12 at best, so it keeps the first maximum; the engine's scores
+    are products of normalised posteriors and tell the cells apart.  The read carries a tie bit of the ULP / NEAR
+    kind (the contract of include/nadavca_hip.h), and the classifier accepts the difference only because of the
+    referee's own tie (tests/fuzz_cases.py: 'referee-tie')."""
+    from fuzz_cases import classify_difference, near_tie_bases
+    from nadavca_amd._lib import TIE_ULP, TIE_NEAR
+    fb, reads = _fuzz_batch(20261006, 8718)
+    mg = dtw.KmerModel(*fb['model'])
+    mo = oracle_port.KmerModel(*fb['model'])
+    got = dtw.refine_alignment_batch(reads, fb['bw'], fb['mel'], mg, fb['tr'])
+    flags = mg.context.last_tie_flags(len(reads))
+    c = fb['cases'][0]
+    exp = np.asarray(oracle_port.refine_alignment(c['signal'], c['reference'], c['context_before'], c['context_after'],
+                                                  c['approximate_alignment'], fb['bw'], fb['mel'], mo,
+                                                  fb['tr'])).reshape(-1, 2)
+    ev = np.asarray(got[0]).reshape(-1, 2)
+    rows = np.nonzero((ev != exp).any(axis=1))[0]
+    assert rows.tolist() == [122] and abs(int(ev[122, 1]) - int(exp[122, 1])) == 1
+    assert flags[0] & (TIE_ULP | TIE_NEAR)
+    assert set(near_tie_bases(c, fb['model'], fb['bw'], fb['mel'], fb['tr']).tolist()) == {122, 123}
+    assert classify_difference(ev, exp, c, fb['model'], fb['k'], fb['central'], fb['alphabet'], fb['bw'], fb['mel'],
+                               fb['tr']) == 'referee-tie'
