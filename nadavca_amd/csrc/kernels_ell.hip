@@ -124,9 +124,13 @@ __device__ __forceinline__ X add_lazy(X a, X b) {
 }
 
 // e(x) as (mantissa in [1,2), exponent): dens::density without its final ldexp
+// (the polynomial without its g^5 term: 1.2e-15 per density, where the log-likelihoods are compared at 1e-9)
 __device__ __forceinline__ X density_x(double x, double mean, double ac, double mc, const double *etab) {
-  const dens::DensHalf h = dens::density_begin(x, mean, ac, mc, etab);
-  return X{h.tj * h.p, h.ki >> dens::ETL};
+  const double d = x - mean;
+  const double y = fma(-(d * d), mc, ac);
+  const double kk = rint(y);
+  const int ki = (int)kk;
+  return X{etab[ki & (dens::ETN - 1)] * dens::dens_poly4(y - kk), ki >> dens::ETL};
 }
 
 // fused_step with lazy sums; gb/ga are the two mixture components at this cell's sample
@@ -173,11 +177,10 @@ __device__ __forceinline__ void fused_step_ring(const HypDesc &d, LaneState<MEL>
   mix.m = mix.m * d.wmul;
   mix.e = mix.e + d.wexp;
   X wn = add_lazy(pred, xm::mul(mix, st.wq[(r + M - 1) % M]));
-#if NVK_ELL_EMASK
+  // Outside its band the wobble value only gets the exponent of a zero (one select instead of three): beside any
+  // real number such a value vanishes exactly (ldexp by -2^28 is 0), beside another of its kind it stays one, and a
+  // total made of nothing else is recognised by its exponent when the hypothesis is finished (below XZ / 2: a zero).
   wn.e = (i >= d.wbs && i <= d.wbe) ? wn.e : xm::XZ;
-#else
-  wn = xm::sel(i >= d.wbs && i <= d.wbe, wn, xm::zero());
-#endif
   st.wq[r] = wn;  // replaces the value of step u - M; the one of step u - MEL is wq[(r + 1) % M]
   X en;
   if (MEL >= 1) {
@@ -190,7 +193,9 @@ __device__ __forceinline__ void fused_step_ring(const HypDesc &d, LaneState<MEL>
   } else {
     en = add_lazy(st.wq[(r + 1) % M], xm::mul(gb, st.em));
   }
-  en = xm::sel(i >= d.elo && i <= d.ebe, en, alt);  // alt: the lane's stream at this cell (see the caller)
+  // alt: the lane's stream at this cell (see the caller).  Only the row's LAST cell is tested: below its first
+  // one the wobble history and the previous value are (such) zeros already.
+  en = xm::sel(i <= d.ebe, en, alt);
   st.em = en;
   if (MEL >= 2) {
 #pragma unroll
@@ -788,9 +793,7 @@ __global__ __launch_bounds__(64, 3) void ell_kernel(EllArgs g) {
         }
         if (is_fin) {
           acc = xm::norm(acc);
-#if NVK_ELL_EMASK
-          if (acc.e < xm::XZ / 2) acc = xm::zero();  // made of nothing but out-of-band values
-#endif
+          if (RING && acc.e < xm::XZ / 2) acc = xm::zero();  // made of nothing but out-of-band values (fused_step_ring)
           out[(size_t)p * alpha + b] = xm::to_log(acc);
         }
       }

@@ -26,15 +26,12 @@
 #ifndef NVK_SLOTS_R
 #define NVK_SLOTS_R 0
 #endif
-#ifndef NVK_ELL_EMASK
-#define NVK_ELL_EMASK 0    // kernels_ell.hip: wobble row masked by its exponent only (experiment, §4.2)
-#endif
 #ifndef NVK_ELL_ABL
 #define NVK_ELL_ABL 0      // kernels_ell.hip, timing only: 1 no hypothesis phase, 2 no sweeps
 #endif
 
 #if !defined(NVK_VARIANT_BUILD) &&                                                                            \
     (NVK_ABL != 0 || NVK_NO_TIEFLAG != 0 || NVK_PAIR_DEBUG != 0 || NVK_NO_PAIR != 0 || NVK_TWO_PHASE != 1 || \
-     NVK_ELL_ABL != 0 || NVK_ELL_EMASK != 0 || NVK_SLOTS_F != 0 || NVK_SLOTS_R != 0 || defined(NVK_FLAG_DEBUG) || defined(NVK_DEBUG_SWITCHES))
+     NVK_ELL_ABL != 0 ||  NVK_SLOTS_F != 0 || NVK_SLOTS_R != 0 || defined(NVK_FLAG_DEBUG) || defined(NVK_DEBUG_SWITCHES))
 #error "a development switch is set in a product build (variant_switches.h): use tools/build_variant.sh"
 #endif
