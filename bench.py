@@ -47,10 +47,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICRO
 # selects, max / shift-add forms) occupies its SIMD for 4 cycles, the plain 32-bit integer ones (v_add_u32,
 # v_sub_u32, v_and_b32, v_mov_b32 incl. its DPP form) for 2 (profiles/ubench_valu_gfx950.txt: 1.06-1.14 ns against
 # 1.85-2.3 ns per wave-instruction).  The hypothesis loop, 5/6 of the kernel's instructions, holds 266 of the
-# second kind among its 905 per 12-step trip (hipcc -S listing of kernels_ell.hip, tools/isa_blocks.py): 3.41
+# second kind among its 854 per 12-step trip (hipcc -S listing of kernels_ell.hip, tools/isa_blocks.py): 3.38
 # cycles per instruction on average.  (Rounds 1-2 used 4 cycles for every instruction; the kernel now runs close
-# enough to the bound for the difference to show: that figure would read 1.04 on 200 000 reads.)
-VALU_CYCLES_PER_INST = (639 * 4 + 266 * 2) / 905.0
+# enough to the bound for the difference to show: that figure would read above 1 on 200 000 reads.)
+VALU_CYCLES_PER_INST = (588 * 4 + 266 * 2) / 854.0
 VALU_PEAK_TLANE = 1024 * 64 * 2.4e9 / VALU_CYCLES_PER_INST / 1e12
 
 
