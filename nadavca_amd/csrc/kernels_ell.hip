@@ -17,7 +17,7 @@
 // emitting row to the neighbour through a small LDS ring.  All probabilities are scaled linear
 // numbers (xmath.h); natural logs are taken once per output value.
 //
-// Sweep rows are kept row-major in a per-slot row store (12 B per cell) so that phase C reads
+// Sweep rows are kept row-major in a per-slot row store (16-byte cells: struct Cell) so that phase C reads
 // them with unit stride.  Phase C packs 8 hypotheses per wave step, 8 lanes each: up to k fused
 // positions plus one closing lane that applies the last wobble row and accumulates
 // sum_x cur[x] * suffix[last+1][x].
@@ -28,14 +28,16 @@
 // exactly the terms that decide such hypotheses.  The default (FAST) variant makes the scaled numbers
 // cheap instead:
 //   * sums are not re-normalised (xm-style frexp) on every operation: add_lazy aligns the two
-//     mantissas and adds, the state is normalised once every 16 steps;
+//     mantissas and adds, the state is normalised once per trip of 12 steps (phase C: a trip is unrolled, so the
+//     history and prefetch slots of a step are constants — fused_step_ring) or every 16 steps (sweeps);
 //   * ONE table-based density per lane (dens.h) delivered directly as (mantissa, exponent); the
 //     mixture's other component and the predecessor value come from the neighbouring lane with DPP row
 //     shifts (lane rho at step u works on the cell lane rho-1 worked on at step u-1) — no LDS traffic;
 //   * the three input streams are prefetched in place (no double-buffer copies); cells outside a
 //     stream's band are redirected to a zero cell of the row store instead of being masked;
 //   * the sweeps use the same arithmetic: a lane's mixture partner is its left neighbour's own density
-//     at the same cell, handed over through the LDS ring with the emitting value, which is normalised
+//     at the same cell, handed over with the emitting value — by a DPP wave rotate at skew 1 (every
+//     config-2-shaped read), through an LDS ring otherwise — which is normalised
 //     at EVERY hand-over (a dominating value passes its mantissa on; a systematic factor per hand-over
 //     would compound to 2^-R or 2^+R along the lanes).
 // The exact variant (NADAVCA_ELL_KERNEL=1) is the original formulation with
