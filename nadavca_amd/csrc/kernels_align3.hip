@@ -1078,11 +1078,79 @@ __global__ __launch_bounds__(64 * W, PHASE == 1 ? (W > 1 ? NVK_LB_REV_TEAM : NVK
     if (gl == 0 && ((amb_x | amb_n | amb_u) != 0 || m.rsv))
       g.ties[rd] = (amb_x != 0 ? NVK_TIE_EXACT : 0) | (amb_n != 0 ? NVK_TIE_NEAR : 0) | (amb_u != 0 ? NVK_TIE_ULP : 0) |
                    (m.rsv ? NVK_TIE_PLATEAU : 0);
-    if (gl == 0) {
+    if (W == 1 && NVK_ABL != 11 && NVK_ABL != 12) {
+      // The walk down the update bits: row r's word tells where row r - 1 starts, a serial chain of ~800 rows per
+      // read.  Run by one lane it was ~60 instructions per row — 9 % of everything the wave issues, and a wave that
+      // shares its SIMD with three sweeping ones gets an issue slot every ~16 cycles whatever the instruction is.
+      // Here the wave prepares 16 rows at a time in its lanes (lane 4 l + q: row r0 - l, its offsets folded into
+      // two constants, and the q-th of four consecutive bit words around the step a straight line through the read
+      // predicts), and the serial part is scalar: three v_readlane, a handful of SALU operations, one v_writelane
+      // for the event boundary, which the lanes store together after the 16 rows.  A word outside the four, or an
+      // empty one, goes the old way.  Same bits, same arithmetic, same result.
+      int32_t *ev = g.out_events + 2 * m.ref_off;
+      const float steps_per_row = (float)n_steps / (float)T;
+      int st = NVK_READ_OK;
+      int r = top;
+      int cur = idx;  // (uniform)
+      while (r >= 0) {
+        const int r0 = r;
+        const int l = lane >> 2, q = lane & 3;
+        const int row = r0 - l;
+        const int off_l = (row >= 0) ? offs[row] : 0;
+        const int pm_l = g.transitions ? ((row - 1) & 1 ? 0 : MEL) : MEL;
+        const int a_l = off_l - t_min;            // u = cur + a
+        const int b_l = t_min - off_l - pm_l;     // next cur = (step of the bit) + b
+        const int u0 = cur + __builtin_amdgcn_readfirstlane(a_l);
+        const int wq = ((u0 - (int)((float)l * steps_per_row)) >> 5) + 1 - q;
+        const uint32_t word = (row >= 1 && wq >= 0) ? bp[(size_t)wq * TL + (row & (TL - 1))] : 0u;
+        int curs = cur;  // lane ll: the event boundary of row r0 - ll
+        int done = 0;
+        for (int ll = 0; ll < 16; ++ll) {
+          curs = (lane == ll) ? cur : curs;
+          done = ll + 1;
+          if (r == 0) {
+            r = -1;
+            break;
+          }
+          const int u = cur + __builtin_amdgcn_readlane(a_l, 4 * ll);
+          int w = u >> 5;
+          const int qi = __builtin_amdgcn_readlane(wq, 4 * ll) - w;  // lane 4 ll holds the highest of the four words
+          uint32_t v = 0;
+          if ((unsigned)qi <= 3u)
+            v = (uint32_t)__builtin_amdgcn_readlane((int)word, 4 * ll + qi) & (0xffffffffu << (31 - (u & 31)));
+          if (v == 0) {  // not among the four, or no bit at or below u in that word: the plain walk for this row
+            v = bp[(size_t)w * TL + (r & (TL - 1))] & (0xffffffffu << (31 - (u & 31)));
+            while (v == 0 && w > 0) {
+              --w;
+              v = bp[(size_t)w * TL + (r & (TL - 1))];
+            }
+            if (v == 0) {
+              st = NVK_READ_RETRY_INTERNAL;
+              if (lane == 0) atomicAdd(g.n_retry, 1);
+              r = -1;
+              break;
+            }
+          }
+          cur = (w << 5) + (31 - (__ffs(v) - 1)) + __builtin_amdgcn_readlane(b_l, 4 * ll);
+          --r;
+        }
+        // the boundaries of rows r0 .. r0 - done + 1, stored by as many lanes
+        if (lane < done) {
+          const int rr = r0 - lane;
+          if (g.transitions) {
+            ev[2 * (rr >> 1) + (rr & 1)] = curs;
+          } else {
+            if (rr > 0) ev[2 * (rr - 1) + 1] = curs;
+            if (rr < top) ev[2 * rr] = curs;
+          }
+        }
+      }
+      if (lane == 0) g.out_status[rd] = st;
+    } else if (gl == 0) {
       int32_t *ev = g.out_events + 2 * m.ref_off;
       int st = NVK_READ_OK;
       int off_r = offs[top];
-      for (int r = top; r >= 0; --r) {
+      for (int r = (NVK_ABL == 11 ? -1 : top); r >= 0; --r) {   // (ablation 11: no traceback)
         const int off_c = off_r;
         if (r > 0) off_r = offs[r - 1];  // next iteration's offset, fetched beside this one's bit words
         if (g.transitions) {
