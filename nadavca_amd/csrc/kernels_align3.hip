@@ -1091,7 +1091,7 @@ __global__ __launch_bounds__(64 * W, PHASE == 1 ? (W > 1 ? NVK_LB_REV_TEAM : NVK
       const float steps_per_row = (float)n_steps / (float)T;
       int st = NVK_READ_OK;
       int r = top;
-      int cur = idx;  // (uniform)
+      int cur = __builtin_amdgcn_readfirstlane(idx);  // the chain below is scalar: every value of it in SGPRs
       while (r >= 0) {
         const int r0 = r;
         const int l = lane >> 2, q = lane & 3;
@@ -1119,10 +1119,11 @@ __global__ __launch_bounds__(64 * W, PHASE == 1 ? (W > 1 ? NVK_LB_REV_TEAM : NVK
           if ((unsigned)qi <= 3u)
             v = (uint32_t)__builtin_amdgcn_readlane((int)word, 4 * ll + qi) & (0xffffffffu << (31 - (u & 31)));
           if (v == 0) {  // not among the four, or no bit at or below u in that word: the plain walk for this row
-            v = bp[(size_t)w * TL + (r & (TL - 1))] & (0xffffffffu << (31 - (u & 31)));
+            v = (uint32_t)__builtin_amdgcn_readfirstlane((int)bp[(size_t)w * TL + (r & (TL - 1))]) &
+                (0xffffffffu << (31 - (u & 31)));
             while (v == 0 && w > 0) {
               --w;
-              v = bp[(size_t)w * TL + (r & (TL - 1))];
+              v = (uint32_t)__builtin_amdgcn_readfirstlane((int)bp[(size_t)w * TL + (r & (TL - 1))]);
             }
             if (v == 0) {
               st = NVK_READ_RETRY_INTERNAL;
