@@ -1078,7 +1078,8 @@ __global__ __launch_bounds__(64 * W, PHASE == 1 ? (W > 1 ? NVK_LB_REV_TEAM : NVK
     if (gl == 0 && ((amb_x | amb_n | amb_u) != 0 || m.rsv))
       g.ties[rd] = (amb_x != 0 ? NVK_TIE_EXACT : 0) | (amb_n != 0 ? NVK_TIE_NEAR : 0) | (amb_u != 0 ? NVK_TIE_ULP : 0) |
                    (m.rsv ? NVK_TIE_PLATEAU : 0);
-    if (W == 1 && NVK_ABL != 11 && NVK_ABL != 12) {
+    if (NVK_ABL != 11 && NVK_ABL != 12) {
+      if (wv == 0) {  // (of a team, its first wave)
       // The walk down the update bits: row r's word tells where row r - 1 starts, a serial chain of ~800 rows per
       // read.  Run by one lane it was ~60 instructions per row — 9 % of everything the wave issues, and a wave that
       // shares its SIMD with three sweeping ones gets an issue slot every ~16 cycles whatever the instruction is.
@@ -1147,6 +1148,7 @@ __global__ __launch_bounds__(64 * W, PHASE == 1 ? (W > 1 ? NVK_LB_REV_TEAM : NVK
         }
       }
       if (lane == 0) g.out_status[rd] = st;
+      }  // (a team's other waves have nothing to do here)
     } else if (gl == 0) {
       int32_t *ev = g.out_events + 2 * m.ref_off;
       int st = NVK_READ_OK;
